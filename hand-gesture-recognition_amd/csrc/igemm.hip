@@ -1,0 +1,256 @@
+// igemm.hip -- NHWC implicit-GEMM on MFMA: conv forward, conv data-gradient, 1x1 conv, Linear.
+//
+//   Out[m][n] = epilogue( sum_k A(m,k) * Wp[n][k] ),   m = (b, oy, ox),  k = (kh, kw, ci)
+//
+// One kernel serves (reference sites in parentheses):
+//   * Conv 3x3 / 1x1 forward            (model/gelan.py:37-45, 56)            gather: iy = oy*s - p + kh
+//   * Conv data-gradient (dgrad)        (autograd of the above)               gather: oy = (iy + p - kh)/s
+//   * proj 1x1                          (model/multitasknet.py:13,26)
+//   * nn.Linear qkv / out / MLP + their dgrad (model/transformer.py:34-37,56-58)
+// through the affine tap map  t = o*mul + kh*sgn + off,  valid iff t % div == 0 and 0 <= t/div < H.
+//
+// Tiling: BM x BN output tile per workgroup, 4 waves (64-wide) in a WGM x WGN grid, each wave an
+// (BM/WGM) x (BN/WGN) sub-tile of 16x16 MFMA fragments; K step = 128 bytes of the reduction
+// axis per row (64 bf16 / 32 f32 -- a whole number of channels of ONE tap since Cin % BK == 0).
+// A and W tiles are staged global -> registers -> LDS (144-byte padded rows: ds_read_b128
+// fragments 2-way conflicts at worst), double buffered, one barrier per K step: the loads of
+// step k+1 are in flight while the MFMAs of step k run.  The accumulator tile is staged through
+// LDS as f32 so the epilogue (bias, GELU, residual, BN partial statistics) is applied row-wise
+// and the stores are 16-byte coalesced along the channel axis.
+//
+// BN statistics (model/gelan.py:46, train mode): every tile writes its per-channel sum and
+// sum-of-squares over the tile's rows to stats[tile_m][2][N]; bn_finalize reduces the slab in
+// tile order -> deterministic, no float atomics.
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+constexpr int ROW_BYTES = 128;          // reduction bytes per row per K step
+constexpr int PITCH_BYTES = 144;        // padded LDS row
+
+template <class T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int BK = ROW_BYTES / (int)sizeof(T);
+    constexpr int PITCH = PITCH_BYTES / (int)sizeof(T);
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int KI = Mma<T>::KI;
+    constexpr int RA = BM * 8 / NT;      // A chunks per thread per K step
+    constexpr int RB = BN * 8 / NT;      // W chunks per thread per K step
+    constexpr int RSTEP = NT / 8;        // rows between a thread's chunks
+    constexpr int CP = BN + 4;           // f32 pitch of the staged C tile
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "loader mapping");
+    static_assert(NT % BN == 0, "stats mapping");
+
+    MTN_DYN_SMEM(smem);
+    T* const sA = reinterpret_cast<T*>(smem);                       // [2][BM][PITCH]
+    T* const sB = sA + 2 * BM * PITCH;                              // [2][BN][PITCH]
+    float* const sC = reinterpret_cast<float*>(smem);               // [BM][CP] (after the K loop)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+
+    // XCD-aware tile order: workgroups that share an XCD (same bid % 8) get consecutive tiles,
+    // n fastest, so the re-reads of one A row-panel by its N/BN tiles hit that XCD's L2.
+    const int tiles_n = p.N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wp);
+
+    // ---- per-thread loader state: RA rows of A (pixel decode), RB rows of W -------------------
+    const int chunk = tid & 7;
+    const int row0 = tid >> 3;
+    int a_y[RA], a_x[RA], a_base[RA];
+    MTN_UNROLL for (int i = 0; i < RA; ++i) {
+        const int m = m0 + row0 + i * RSTEP;
+        if (m < p.M) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_y[i] = oy * p.mul + p.off;
+            a_x[i] = ox * p.mul + p.off;
+            a_base[i] = b * p.H * p.W;
+        } else {
+            a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0;
+        }
+    }
+    const int dshift = p.div >> 1, dmask = p.div - 1;     // div in {1,2}
+
+    chunk16 ra[RA], rb[RB];
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        MTN_UNROLL for (int i = 0; i < RA; ++i) {
+            const int ty = a_y[i] + kh * p.sgn, tx = a_x[i] + kw * p.sgn;
+            const int iy = ty >> dshift, ix = tx >> dshift;
+            const bool ok = (ty >= 0) && (tx >= 0) && ((ty & dmask) == 0) && ((tx & dmask) == 0) &&
+                            (iy < p.H) && (ix < p.W);
+            if (ok) {
+                const long off = (long)(a_base[i] + iy * p.W + ix) * p.lda + c0 + chunk * VEC;
+                ra[i] = *reinterpret_cast<const chunk16*>(gA + off);
+            } else {
+                ra[i] = zero_chunk();
+            }
+        }
+        MTN_UNROLL for (int i = 0; i < RB; ++i) {
+            const long off = (long)(n0 + row0 + i * RSTEP) * p.K + k0 + chunk * VEC;
+            rb[i] = *reinterpret_cast<const chunk16*>(gW + off);
+        }
+    };
+    auto store_tiles = [&](int stage) {
+        T* a = sA + stage * BM * PITCH;
+        T* b = sB + stage * BN * PITCH;
+        MTN_UNROLL for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<chunk16*>(a + (row0 + i * RSTEP) * PITCH + chunk * VEC) = ra[i];
+        MTN_UNROLL for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<chunk16*>(b + (row0 + i * RSTEP) * PITCH + chunk * VEC) = rb[i];
+    };
+
+    f32x4_t acc[FM][FN];
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
+
+    const int KT = p.K / BK;
+    const int frow = lane & 15;
+    const int fk = (lane >> 4) * (KI / 4);
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tiles(kt + 1);
+        const T* a = sA + cur * BM * PITCH + (wm * WM + frow) * PITCH + fk;
+        const T* b = sB + cur * BN * PITCH + (wn * WN + frow) * PITCH + fk;
+        MTN_UNROLL for (int ks = 0; ks < BK / KI; ++ks) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = Mma<T>::load(a + i * 16 * PITCH + ks * KI);
+            MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = Mma<T>::load(b + j * 16 * PITCH + ks * KI);
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < KT) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (f32) -> row-wise fused math -> 16-byte stores ----------
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j)
+            MTN_UNROLL for (int r = 0; r < 4; ++r)
+                sC[(wm * WM + i * 16 + 4 * (lane >> 4) + r) * CP + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+
+    T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
+    T* __restrict__ gAux = reinterpret_cast<T*>(p.aux_out);
+    const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
+    constexpr int CPR = BN / VEC;     // chunks per row
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
+        const int row = idx / CPR, col = (idx - row * CPR) * VEC;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float v[VEC];
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = sC[row * CP + col + e];
+        if (p.bias) {
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += p.bias[n0 + col + e];
+        }
+        if (p.act == MTN_ACT_GELU) {
+            if (gAux) *reinterpret_cast<chunk16*>(gAux + (long)m * p.ld_aux + n0 + col) = pack<T>(v);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = geluf_(v[e]);
+        }
+        if (gR) {
+            float rr[VEC];
+            unpack<T>(*reinterpret_cast<const chunk16*>(gR + (long)m * p.ldr + n0 + col), rr);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += rr[e];
+        }
+        const chunk16 o = pack<T>(v);
+        *reinterpret_cast<chunk16*>(gO + (long)m * p.ldc + n0 + col) = o;
+        if (p.stats) {          // statistics of the values exactly as stored
+            float w[VEC];
+            unpack<T>(o, w);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) sC[row * CP + col + e] = w[e];
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        constexpr int PARTS = NT / BN;
+        const int col = tid % BN, part = tid / BN;
+        float s = 0.f, ss = 0.f;
+        const int rows = (p.M - m0 < BM) ? (p.M - m0) : BM;
+        for (int r = part; r < rows; r += PARTS) {
+            const float x = sC[r * CP + col];
+            s += x; ss += x * x;
+        }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [PARTS][2][BN]
+        red[(part * 2 + 0) * BN + col] = s;
+        red[(part * 2 + 1) * BN + col] = ss;
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.f;
+            MTN_UNROLL for (int q = 0; q < PARTS; ++q) t += red[(q * 2 + which) * BN + c];
+            p.stats[((long)tile_m * 2 + which) * p.N + n0 + c] = t;
+        }
+    }
+}
+
+template <class T, int BM, int BN, int WGM, int WGN>
+int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr size_t lds_ab = 2 * (size_t)(BM + BN) * PITCH_BYTES;
+    constexpr size_t lds_c = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
+#ifndef MTN_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+#endif
+    const int tiles = mtn_cdiv(p.M, BM) * (p.N / BN);
+    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN>), dim3(tiles), dim3(NT), lds, stream, p);
+    return mtn_check_launch("igemm");
+}
+
+template <class T>
+int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
+    if (p.N % 128 == 0 && p.M >= 128 * 64) return launch_igemm<T, 128, 128, 2, 2>(p, stream);
+    if (p.N % 128 == 0) return launch_igemm<T, 64, 128, 1, 4>(p, stream);
+    return launch_igemm<T, 128, 64, 4, 1>(p, stream);
+}
+
+}  // namespace
+
+int mtn_igemm_tiles_m(int M, int N) {
+    if (N % 128 == 0 && M >= 128 * 64) return mtn_cdiv(M, 128);
+    if (N % 128 == 0) return mtn_cdiv(M, 64);
+    return mtn_cdiv(M, 128);
+}
+
+int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
+    const int bk = dtype == MTN_BF16 ? 64 : 32;
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "igemm: bad dtype %d", dtype);
+    MTN_REQUIRE(p.M > 0 && p.N > 0 && p.N % 64 == 0, "igemm: N=%d must be a positive multiple of 64 (M=%d)", p.N, p.M);
+    MTN_REQUIRE(p.Cin % bk == 0, "igemm: Cin=%d must be a multiple of %d", p.Cin, bk);
+    MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "igemm: K=%d != KH*KW*Cin", p.K);
+    MTN_REQUIRE(p.div == 1 || p.div == 2, "igemm: div=%d", p.div);
+    MTN_REQUIRE(p.lda % (bk / 8) == 0 && p.ldc % (bk / 8) == 0, "igemm: lda/ldc must keep 16-byte alignment");
+    MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "igemm: M=%d != B*OH*OW", p.M);
+    MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 31) && (long)p.M * p.ldc < (1L << 31), "igemm: tensor too large for 32-bit offsets");
+    MTN_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.Wp | (uintptr_t)p.Out | (uintptr_t)p.res | (uintptr_t)p.aux_out) % 16 == 0, "igemm: pointers must be 16-byte aligned");
+    return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);
+}

@@ -1,0 +1,41 @@
+// mtn_rt.h -- the one place that knows how kernels are compiled and launched.
+//
+// Product build (hipcc --offload-arch=gfx950): real HIP.  Test build (-DMTN_EMU, g++): the
+// fiber executor in tests/emu/hipemu.h runs the same kernel sources on the CPU so their logic
+// can be checked without a GPU.  The product library is never built with MTN_EMU.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#ifdef MTN_EMU
+#include "hipemu.h"
+#define MTN_LAUNCH(kern, grid, block, smem, stream, ...) \
+    MTN_EMU_LAUNCH(kern, grid, block, smem, stream, __VA_ARGS__)
+#define MTN_DYN_SMEM(name) char* name = emu::g_dyn_smem
+#define MTN_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define MTN_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+#define MTN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define MTN_UNROLL _Pragma("unroll")
+#endif
+
+// status codes of the C ABI (include/mtn.h)
+#define MTN_OK 0
+#define MTN_ERR_BAD_ARG 1
+#define MTN_ERR_LAUNCH 2
+#define MTN_ERR_UNSUPPORTED 3
+
+void mtn_set_error(const char* fmt, ...);
+int mtn_check_launch(const char* what);
+
+#define MTN_REQUIRE(cond, ...)                     \
+    do {                                           \
+        if (!(cond)) {                             \
+            mtn_set_error(__VA_ARGS__);            \
+            return MTN_ERR_BAD_ARG;                \
+        }                                          \
+    } while (0)
+
+static inline int mtn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

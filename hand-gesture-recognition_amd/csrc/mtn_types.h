@@ -1,0 +1,142 @@
+// mtn_types.h -- element types, 16-byte vector access and MFMA wrappers shared by all kernels.
+//
+// Two storage precisions run through the SAME kernels (template parameter T):
+//   bf16_t : throughput mode -- bf16 activations/weights, MFMA bf16, fp32 accumulate
+//   float  : validation mode -- fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32),
+//            the mode the 1e-3 parity gate against the fp32 reference is run in.
+#pragma once
+#include "mtn_rt.h"
+
+struct bf16_t { unsigned short v; };
+
+#ifdef MTN_EMU
+typedef emu::bf16x8 bf16x8_t;
+typedef emu::f32x4 f32x4_t;
+typedef emu::f32x16 f32x16_t;
+__device__ inline float bf2f(bf16_t h) { return emu::bf2f(h.v); }
+__device__ inline bf16_t f2bf(float f) {      // round-to-nearest-even, NaN stays NaN
+    uint32_t u; std::memcpy(&u, &f, 4);
+    bf16_t r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) { r.v = (unsigned short)((u >> 16) | 0x40); return r; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.v = (unsigned short)(u >> 16);
+    return r;
+}
+#else
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h.v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // v_cvt_pk_bf16_f32: RNE, keeps NaN
+    bf16_t r; r.v = __builtin_bit_cast(unsigned short, (__bf16)f); return r;
+}
+#endif
+
+template <class T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
+template <class T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
+// value as it will read back from storage of type T
+template <class T> __device__ __forceinline__ float round_to(float x) { return to_f<T>(from_f<T>(x)); }
+
+// 16-byte chunk: the unit of every global<->LDS move (8 bf16 or 4 f32)
+struct alignas(16) chunk16 { unsigned w[4]; };
+template <class T> struct Vec { static constexpr int N = 16 / sizeof(T); };
+
+template <class T> __device__ __forceinline__ void unpack(const chunk16& c, float* f);
+template <> __device__ __forceinline__ void unpack<float>(const chunk16& c, float* f) {
+#ifdef MTN_EMU
+    std::memcpy(f, c.w, 16);
+#else
+    MTN_UNROLL for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c.w[i]);
+#endif
+}
+template <> __device__ __forceinline__ void unpack<bf16_t>(const chunk16& c, float* f) {
+    MTN_UNROLL for (int i = 0; i < 4; ++i) {
+        bf16_t lo, hi; lo.v = (unsigned short)(c.w[i] & 0xffffu); hi.v = (unsigned short)(c.w[i] >> 16);
+        f[2 * i] = bf2f(lo); f[2 * i + 1] = bf2f(hi);
+    }
+}
+template <class T> __device__ __forceinline__ chunk16 pack(const float* f);
+template <> __device__ __forceinline__ chunk16 pack<float>(const float* f) {
+    chunk16 c;
+#ifdef MTN_EMU
+    std::memcpy(c.w, f, 16);
+#else
+    MTN_UNROLL for (int i = 0; i < 4; ++i) c.w[i] = __float_as_uint(f[i]);
+#endif
+    return c;
+}
+template <> __device__ __forceinline__ chunk16 pack<bf16_t>(const float* f) {
+    chunk16 c;
+    MTN_UNROLL for (int i = 0; i < 4; ++i)
+        c.w[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
+    return c;
+}
+__device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0u; return c; }
+
+// ---- MFMA, 16x16 output tile -------------------------------------------------------------
+// Mma<T>::KI = K depth of one instruction; Frag = one lane's A or B operand.
+// Lane map (cdna_hip_programming.md section 3): bf16: A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
+// f32: A[l&15][l>>4], B[l>>4][l&15];  D: col = l&15, row = 4*(l>>4)+reg.
+template <class T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KI = 32;
+    typedef bf16x8_t Frag;
+    // fragment = 16 contiguous bytes at row-major [row][k0 + 8*(lane>>4)]
+    static __device__ __forceinline__ Frag load(const bf16_t* p) {
+#ifdef MTN_EMU
+        Frag f; std::memcpy(&f, p, 16); return f;
+#else
+        return *reinterpret_cast<const Frag*>(p);
+#endif
+    }
+    static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
+#ifdef MTN_EMU
+        return emu::mfma_16x16x32_bf16(a, b, c);
+#else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KI = 4;
+    typedef float Frag;
+    static __device__ __forceinline__ Frag load(const float* p) { return *p; }
+    static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
+#ifdef MTN_EMU
+        return emu::mfma_16x16x4_f32(a, b, c);
+#else
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+    }
+};
+
+__device__ __forceinline__ f32x4_t zero4() {
+    f32x4_t z; z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f; return z;
+}
+
+// ---- small math -----------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad_(float x) {   // d/dx x*sigmoid(x)
+    const float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    MTN_UNROLL for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    MTN_UNROLL for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}

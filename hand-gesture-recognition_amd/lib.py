@@ -1,0 +1,78 @@
+"""ctypes binding of the C ABI declared in ``include/mtn.h``.
+
+The product library is ``libmtn_hip.so`` (hipcc, gfx950) next to this file.  There is NO
+fallback: if it is missing or a call fails, a RuntimeError is raised.  (``use_library`` exists so
+the CPU kernel-logic tests can point the same host code at ``libmtn_emu.so``; nothing in the
+package calls it.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "libmtn_hip.so")
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes  (restype is int unless listed in _RESTYPES)
+_PROTOS = {
+    "mtn_abi_version": [],
+    "mtn_conv_stats_tiles": [_i, _i],
+    "mtn_conv_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mtn_conv_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mtn_linear_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+}
+_RESTYPES = {}
+_STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles"}   # return a value, not a status
+
+_lib = None
+_lib_path = None
+
+
+def _bind(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` (or `make -C hand-gesture-recognition_amd/csrc hip`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.mtn_last_error.restype = C.c_char_p
+    lib.mtn_last_error.argtypes = []
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _i)
+    return lib
+
+
+def get():
+    global _lib, _lib_path
+    if _lib is None:
+        _lib = _bind(HIP_LIB)
+        _lib_path = HIP_LIB
+    return _lib
+
+
+def use_library(path):
+    """Bind a specific build of the C ABI (tests only)."""
+    global _lib, _lib_path
+    _lib = _bind(path)
+    _lib_path = path
+    return _lib
+
+
+def loaded_path():
+    return _lib_path
+
+
+def exported_symbols():
+    return sorted(_PROTOS) + ["mtn_last_error"]
+
+
+def call(name, *args):
+    lib = get()
+    rc = getattr(lib, name)(*args)
+    if name in _STATUS_FREE:
+        return rc
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {lib.mtn_last_error().decode()}")
+    return rc

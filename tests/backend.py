@@ -1,0 +1,60 @@
+"""Backend selection for kernel tests.
+
+``hip``: the product library libmtn_hip.so on cuda:0 (tests carry @pytest.mark.gpu).
+``emu``: the same kernel sources compiled for the CPU fiber executor (tests/emu/hipemu.h),
+         used by the ``not gpu`` suite to check kernel logic at tiny sizes.
+"""
+import os
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "hand-gesture-recognition_amd", "csrc")
+EMU_LIB = os.path.join(ROOT, "hand-gesture-recognition_amd", "libmtn_emu.so")
+
+_built = {}
+
+
+def _ensure_emu():
+    if "emu" not in _built:
+        subprocess.run(["make", "-C", CSRC, "-j4", "emu"], check=True, stdout=subprocess.DEVNULL)
+        _built["emu"] = True
+
+
+class Backend:
+    def __init__(self, name):
+        from hand_gesture_recognition_amd import lib
+        self.name = name
+        if name == "emu":
+            _ensure_emu()
+            lib.use_library(EMU_LIB)
+            self.device = torch.device("cpu")
+        else:
+            lib.use_library(lib.HIP_LIB)
+            assert torch.cuda.is_available(), "hip backend needs a GPU"
+            self.device = torch.device("cuda:0")
+
+    def sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+
+
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+DTYPES = [pytest.param(torch.float32, id="f32"), pytest.param(torch.bfloat16, id="bf16")]
+
+
+@pytest.fixture(params=BACKENDS)
+def be(request):
+    return Backend(request.param)
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def tol(dtype, f32=1e-4, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16

@@ -1,0 +1,82 @@
+"""Micro-benchmarks of individual HIP kernels at BASELINE config-2 sizes (B=256, 192x192).
+
+Usage (GPU box): python tools/bench_kernels.py [--batch 256] [--filter conv]
+Prints one line per case: time (HIP events on the launch stream), TFLOP/s, GB/s (algorithmic).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hand_gesture_recognition_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda:0")
+    B = a.batch
+    esz = 2 if dt == torch.bfloat16 else 4
+    convs = [  # name, H, W, Cin, Cout, k, s
+        ("conv2", 96, 96, 64, 128, 3, 2),
+        ("s1.cv1", 48, 48, 128, 128, 1, 1), ("s1.3x3", 48, 48, 64, 64, 3, 1), ("s1.cv4", 48, 48, 256, 128, 1, 1),
+        ("down1", 48, 48, 128, 256, 3, 2),
+        ("s2.cv1", 24, 24, 256, 256, 1, 1), ("s2.3x3", 24, 24, 128, 128, 3, 1), ("s2.cv4", 24, 24, 512, 256, 1, 1),
+        ("down2", 24, 24, 256, 512, 3, 2),
+        ("s3.cv1", 12, 12, 512, 512, 1, 1), ("s3.3x3", 12, 12, 256, 256, 3, 1), ("s3.cv4", 12, 12, 1024, 512, 1, 1),
+        ("proj", 12, 12, 512, 256, 1, 1),
+    ]
+    for name, H, W, Cin, Cout, k, s in convs:
+        if a.filter and a.filter not in "conv_fwd." + name:
+            continue
+        OH, OW = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        x = torch.randn(B, H, W, Cin, device=dev).to(dt)
+        w = (torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(dt)
+        y = torch.empty(B, OH, OW, Cout, device=dev, dtype=dt)
+        M = B * OH * OW
+        stats = torch.empty(ops.conv_stats_tiles(M, Cout), 2, Cout, device=dev)
+        t = timeit(lambda: ops.conv_fwd(x, w, y, stats, k, s))
+        fl = 2.0 * M * Cout * k * k * Cin
+        by = (x.numel() + y.numel() + w.numel()) * esz
+        print(f"conv_fwd.{name:8s} M={M:8d} N={Cout:4d} K={k*k*Cin:5d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s")
+        if k == 3 or name.endswith(("cv1", "cv4")):
+            dy = torch.randn(B, OH, OW, Cout, device=dev).to(dt)
+            wt = (torch.randn(Cin, k, k, Cout, device=dev) / (Cout * k * k) ** 0.5).to(dt)
+            dx = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
+            t = timeit(lambda: ops.conv_dgrad(dy, wt, dx, None, k, s))
+            print(f"conv_dgrad.{name:6s} M={B*H*W:8d} N={Cin:4d} K={k*k*Cout:5d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s (useful)  {by/t/1e9:7.0f} GB/s")
+    # ViT linears: M = B*145
+    M = B * 145
+    for name, K, N in (("qkv", 256, 768), ("out", 256, 256)):
+        if a.filter and a.filter not in "linear." + name:
+            continue
+        x = torch.randn(M, K, device=dev).to(dt)
+        w = (torch.randn(N, K, device=dev) / 16).to(dt)
+        o = torch.empty(M, N, device=dev, dtype=dt)
+        t = timeit(lambda: ops.linear_fwd(x, w, o))
+        fl = 2.0 * M * N * K
+        by = (x.numel() + o.numel() + w.numel()) * esz
+        print(f"linear.{name:10s} M={M:8d} N={N:4d} K={K:5d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
