@@ -1,0 +1,327 @@
+// bn.hip -- train-mode BatchNorm2d + SiLU (+ residual) around the conv kernels, forward and backward.
+//
+// Reference: Conv.forward = act(bn(conv(x))) (model/gelan.py:46,56), ResBasicBlock.forward =
+// SiLU(x + bn(conv(...))) (model/gelan.py:78-87).  nn.BatchNorm2d defaults: eps 1e-5, momentum
+// 0.1, batch mean / biased variance for normalisation, unbiased variance into running_var.
+//
+// Forward:  conv epilogue -> stats[tile][2][C] partial sums           (igemm.hip / conv1.hip)
+//           rowblock_sum  -> [R][2][C]   (only when there are many tiles)
+//           bn_finalize   -> scale = gamma*rstd, shift = beta - mean*scale, running stats
+//           bn_act_fwd    -> out = act(y*scale + shift [+ res])       (HBM-bound, 16-byte lanes)
+// Backward: bn_bwd_reduce -> partial sums of dz and dz*xhat, dz = dout * act'(.)
+//           (rowblock_sum) + bn_bwd_finalize -> dgamma, dbeta, mean coefficients
+//           bn_bwd_apply  -> dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)), residual gradient
+// All reductions are slab + ordered sum: deterministic, no float atomics.
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+// out[rb][c] = sum of in[r][c] over the rb-th block of rows_per_block rows
+__global__ __launch_bounds__(256) void rowblock_sum_kernel(const float* __restrict__ in, int rows, int W,
+                                                           int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (c < W)
+        for (int r = r0 + tl; r < r1; r += 4) s += in[(long)r * W + c];
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0 && c < W) out[(long)blockIdx.y * W + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+// block = 4 row-lanes x 64 channels; returns (sum over R rows of part[r][which][c]) in double
+__device__ __forceinline__ void sum2_rows(const float* __restrict__ part, int R, int C, int c, bool valid,
+                                          double& s0, double& s1) {
+    __shared__ double red[2][4][64];
+    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    if (valid)
+        for (int r = tl; r < R; r += 4) {
+            a += (double)part[((long)r * 2 + 0) * C + c];
+            b += (double)part[((long)r * 2 + 1) * C + c];
+        }
+    red[0][tl][cl] = a;
+    red[1][tl][cl] = b;
+    __syncthreads();
+    s0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    s1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          long long* __restrict__ nbt, float momentum, float eps,
+                                                          float* __restrict__ scale_shift, float* __restrict__ mean_rstd) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool valid = c < C;
+    double s, ss;
+    sum2_rows(part, R, C, c, valid, s, ss);
+    if ((threadIdx.x >> 6) == 0 && valid) {
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        scale_shift[c] = sc;
+        scale_shift[C + c] = beta[c] - (float)mean * sc;
+        mean_rstd[c] = (float)mean;
+        mean_rstd[C + c] = rstd;
+        if (rmean) {
+            const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ ss,
+                                                         const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
+                                                         int M, int C, int act) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int cpr = C / VEC;
+    const long total = (long)M * cpr;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / cpr), c = (int)(idx - (long)m * cpr) * VEC;
+        float v[VEC];
+        unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * ss[c + e] + ss[C + c + e];
+        if (res) {
+            float r[VEC];
+            unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += r[e];
+        }
+        if (act == MTN_ACT_SILU) {
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = siluf_(v[e]);
+        }
+        *reinterpret_cast<chunk16*>(out + (long)m * ldo + c) = pack<T>(v);
+    }
+}
+
+// dz for one 16-byte chunk; xh = xhat.  pre-activation = y*scale+shift (+res)
+template <class T, int VEC>
+__device__ __forceinline__ void bn_dz(const T* __restrict__ dout, int lddo, const T* __restrict__ y, int ldy,
+                                      const T* __restrict__ res, int ldr, const float* __restrict__ ss,
+                                      const float* __restrict__ mr, int C, int act, int m, int c, float* dz, float* xh) {
+    float g[VEC], v[VEC];
+    unpack<T>(*reinterpret_cast<const chunk16*>(dout + (long)m * lddo + c), g);
+    unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
+    MTN_UNROLL for (int e = 0; e < VEC; ++e) xh[e] = (v[e] - mr[c + e]) * mr[C + c + e];
+    if (act == MTN_ACT_SILU) {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * ss[c + e] + ss[C + c + e];
+        if (res) {
+            float r[VEC];
+            unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += r[e];
+        }
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] = g[e] * silu_grad_(v[e]);
+    } else {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] = g[e];
+    }
+}
+
+// partial[blockIdx.x][2][C]: sum dz, sum dz*xhat over this block's rows
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ y,
+                                                            int ldy, const T* __restrict__ res, int ldr,
+                                                            const float* __restrict__ ss, const float* __restrict__ mr,
+                                                            int M, int C, int act, int rows_per_block,
+                                                            float* __restrict__ partial) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    MTN_DYN_SMEM(smem);
+    float* red = reinterpret_cast<float*>(smem);        // [rl][2][C]
+    const int cpr = C / VEC;
+    const int rl_n = 256 / cpr;                         // row lanes
+    const int rl = threadIdx.x / cpr, c = (threadIdx.x % cpr) * VEC;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s0[VEC], s1[VEC];
+    MTN_UNROLL for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    if (rl < rl_n)
+        for (int m = r0 + rl; m < r1; m += rl_n) {
+            float dz[VEC], xh[VEC];
+            bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, ss, mr, C, act, m, c, dz, xh);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) { s0[e] += dz[e]; s1[e] += dz[e] * xh[e]; }
+        }
+    if (rl < rl_n) {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+            red[(rl * 2 + 0) * C + c + e] = s0[e];
+            red[(rl * 2 + 1) * C + c + e] = s1[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float t = 0.f;
+        for (int q = 0; q < rl_n; ++q) t += red[q * 2 * C + i];
+        partial[(long)blockIdx.x * 2 * C + i] = t;
+    }
+}
+
+// dgamma = sum dz*xhat, dbeta = sum dz; coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool valid = c < C;
+    double s0, s1;
+    sum2_rows(part, R, C, c, valid, s0, s1);
+    if ((threadIdx.x >> 6) == 0 && valid) {
+        dbeta[c] = (float)s0;
+        dgamma[c] = (float)s1;
+        coef[c] = (float)(s0 / count);
+        coef[C + c] = (float)(s1 / count);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ y,
+                                                           int ldy, const T* __restrict__ res, int ldr,
+                                                           const float* __restrict__ ss, const float* __restrict__ mr,
+                                                           const float* __restrict__ coef, T* __restrict__ dy, int lddy,
+                                                           T* __restrict__ dres, int lddres, const T* __restrict__ extra,
+                                                           int ldextra, int M, int C, int act) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int cpr = C / VEC;
+    const long total = (long)M * cpr;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / cpr), c = (int)(idx - (long)m * cpr) * VEC;
+        float dz[VEC], xh[VEC], o[VEC];
+        bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, ss, mr, C, act, m, c, dz, xh);
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) o[e] = ss[c + e] * (dz[e] - coef[c + e] - xh[e] * coef[C + c + e]);
+        *reinterpret_cast<chunk16*>(dy + (long)m * lddy + c) = pack<T>(o);
+        if (dres) {          // gradient of the residual input (= dz, the pre-activation gradient)
+            if (extra) {
+                float x[VEC];
+                unpack<T>(*reinterpret_cast<const chunk16*>(extra + (long)m * ldextra + c), x);
+                MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] += x[e];
+            }
+            *reinterpret_cast<chunk16*>(dres + (long)m * lddres + c) = pack<T>(dz);
+        }
+    }
+}
+
+inline int ew_grid(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+// ---- host-side launchers -----------------------------------------------------------------------
+static const int kRowsPerBlock = 128;     // rows folded by one rowblock_sum block
+static const int kBwdRows = 256;          // rows per bn_bwd_reduce block (upper bound, see below)
+
+int mtn_reduce_rows_needed(int rows) { return rows > kRowsPerBlock ? rows + mtn_cdiv(rows, kRowsPerBlock) : rows; }
+
+// reduces part[rows][W] in place-adjacent scratch; returns pointer/rows of the (small) slab to finalize
+static int fold_rows(const float*& part, int& rows, int W, hipStream_t stream) {
+    if (rows <= kRowsPerBlock) return MTN_OK;
+    const int R = mtn_cdiv(rows, kRowsPerBlock);
+    float* out = const_cast<float*>(part) + (long)rows * W;
+    MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(256), 0, stream, part, rows, W, kRowsPerBlock, out);
+    part = out;
+    rows = R;
+    return mtn_check_launch("rowblock_sum");
+}
+
+int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float* gamma, const float* beta,
+                        float* rmean, float* rvar, long long* nbt, float momentum, float eps, float* scale_shift,
+                        float* mean_rstd, hipStream_t stream) {
+    MTN_REQUIRE(tiles > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
+    MTN_REQUIRE(tiles <= kRowsPerBlock * kRowsPerBlock, "bn_finalize: too many stat tiles (%d)", tiles);
+    const float* part = stats;
+    int rows = tiles;
+    int rc = fold_rows(part, rows, 2 * C, stream);
+    if (rc) return rc;
+    MTN_LAUNCH(bn_finalize_kernel, dim3(mtn_cdiv(C, 64)), dim3(256), 0, stream, part, rows, C, (float)count, gamma, beta,
+               rmean, rvar, nbt, momentum, eps, scale_shift, mean_rstd);
+    return mtn_check_launch("bn_finalize");
+}
+
+int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res, int ldr, void* out, int ldo, int dtype,
+                       int M, int C, int act, hipStream_t stream) {
+    const int vec = dtype == MTN_BF16 ? 8 : 4;
+    MTN_REQUIRE(C % vec == 0 && ldy % vec == 0 && ldo % vec == 0 && (!res || ldr % vec == 0), "bn_act_fwd: alignment");
+    MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "bn_act_fwd: act=%d", act);
+    const long total = (long)M * (C / vec);
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(bn_act_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16_t*)y, ldy, ss,
+                   (const bf16_t*)res, ldr, (bf16_t*)out, ldo, M, C, act);
+    else
+        MTN_LAUNCH(bn_act_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)y, ldy, ss,
+                   (const float*)res, ldr, (float*)out, ldo, M, C, act);
+    return mtn_check_launch("bn_act_fwd");
+}
+
+int mtn_bn_bwd_blocks(int M) { return mtn_cdiv(M, kBwdRows); }
+
+int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
+    const int vec = dtype == MTN_BF16 ? 8 : 4;
+    const int cpr = a.C / vec;
+    MTN_REQUIRE(a.C % vec == 0 && cpr <= 256 && 256 % cpr == 0, "bn_bwd: C=%d unsupported", a.C);
+    MTN_REQUIRE(a.act == MTN_ACT_NONE || a.act == MTN_ACT_SILU, "bn_bwd: act=%d", a.act);
+    MTN_REQUIRE(a.act == MTN_ACT_SILU || !a.res, "bn_bwd: residual needs SiLU");
+    const int blocks = mtn_bn_bwd_blocks(a.M);
+    MTN_REQUIRE(blocks <= kRowsPerBlock * kRowsPerBlock, "bn_bwd: M too large");
+    const size_t lds = (size_t)(256 / cpr) * 2 * a.C * sizeof(float);
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)a.dout, a.lddo,
+                   (const bf16_t*)a.y, a.ldy, (const bf16_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
+                   kBwdRows, a.partial);
+    else
+        MTN_LAUNCH(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), lds, stream, (const float*)a.dout, a.lddo,
+                   (const float*)a.y, a.ldy, (const float*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
+                   kBwdRows, a.partial);
+    int rc = mtn_check_launch("bn_bwd_reduce");
+    if (rc) return rc;
+    const float* part = a.partial;
+    int rows = blocks;
+    rc = fold_rows(part, rows, 2 * a.C, stream);
+    if (rc) return rc;
+    MTN_LAUNCH(bn_bwd_finalize_kernel, dim3(mtn_cdiv(a.C, 64)), dim3(256), 0, stream, part, rows, a.C, (float)a.M,
+               a.dgamma, a.dbeta, a.coef);
+    rc = mtn_check_launch("bn_bwd_finalize");
+    if (rc) return rc;
+    const long total = (long)a.M * cpr;
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16_t*)a.dout, a.lddo,
+                   (const bf16_t*)a.y, a.ldy, (const bf16_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.coef,
+                   (bf16_t*)a.dy, a.lddy, (bf16_t*)a.dres, a.lddres, (const bf16_t*)a.extra, a.ldextra, a.M, a.C, a.act);
+    else
+        MTN_LAUNCH(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)a.dout, a.lddo,
+                   (const float*)a.y, a.ldy, (const float*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.coef,
+                   (float*)a.dy, a.lddy, (float*)a.dres, a.lddres, (const float*)a.extra, a.ldextra, a.M, a.C, a.act);
+    return mtn_check_launch("bn_bwd_apply");
+}
+
+// generic ordered column sum of an f32 slab: out[c] = sum_r in[r][c]  (bias / LayerNorm affine grads)
+namespace {
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int R, int W,
+                                                              float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < W)
+        for (int r = tl; r < R; r += 4) s += part[(long)r * W + c];
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0 && c < W) out[c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+}  // namespace
+
+int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream) {
+    MTN_REQUIRE(rows > 0 && W > 0 && rows <= kRowsPerBlock * kRowsPerBlock, "colsum: bad sizes (%d x %d)", rows, W);
+    const float* part = slab;
+    int rc = fold_rows(part, rows, W, stream);
+    if (rc) return rc;
+    MTN_LAUNCH(colsum_finalize_kernel, dim3(mtn_cdiv(W, 64)), dim3(256), 0, stream, part, rows, W, out);
+    return mtn_check_launch("colsum");
+}

@@ -79,4 +79,93 @@ int mtn_linear_fwd(const void* x, int ldx, const void* w, const float* bias, int
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
+static int conv_wgrad_args(WgradArgs& p, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    const int pad = ksize / 2;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin;
+    p.OH = (H + 2 * pad - ksize) / stride + 1;
+    p.OW = (W + 2 * pad - ksize) / stride + 1;
+    p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
+    p.M = B * p.OH * p.OW; p.N = Cout; p.K = ksize * ksize * Cin;
+    if (Cout % 64 != 0 || Cin % 64 != 0) { mtn_set_error("wgrad: Cout=%d, Cin=%d must be multiples of 64", Cout, Cin); return 1; }
+    p.splits = mtn_wgrad_splits(p.M, p.N, p.K, Cin, dtype, &p.rows_per_split);
+    return 0;
+}
+
+size_t mtn_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    WgradArgs p{};
+    if (conv_wgrad_args(p, dtype, B, H, W, Cin, Cout, ksize, stride)) return 0;
+    return (size_t)p.splits * p.N * p.K * sizeof(float);
+}
+
+int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                   size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                   int stride, void* stream) {
+    MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_wgrad: ksize=%d", ksize);
+    MTN_REQUIRE(stride == 1 || stride == 2, "conv_wgrad: stride=%d", stride);
+    WgradArgs p{};
+    if (conv_wgrad_args(p, dtype, B, H, W, Cin, Cout, ksize, stride)) return MTN_ERR_BAD_ARG;
+    MTN_REQUIRE(ws_bytes >= (size_t)p.splits * p.N * p.K * sizeof(float), "conv_wgrad: workspace too small");
+    p.dY = dy; p.lddy = lddy; p.X = x; p.ldx = ldx; p.partial = (float*)workspace; p.dW = dw;
+    return mtn_wgrad_run(p, dtype, (hipStream_t)stream);
+}
+
+size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K) {
+    return mtn_conv_wgrad_workspace_bytes(dtype, M, 1, 1, K, N, 1, 1);
+}
+
+int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                     size_t ws_bytes, int dtype, int M, int N, int K, void* stream) {
+    return mtn_conv_wgrad(x, ldx, dy, lddy, dw, workspace, ws_bytes, dtype, M, 1, 1, K, N, 1, 1, stream);
+}
+
+int mtn_conv1_stats_tiles(int B, int H, int W) { return mtn_conv1_tiles((long)B * (H / 2) * (W / 2)); }
+
+int mtn_conv1_fwd(const float* x_nchw, const void* w, void* y, float* stats, int dtype, int B, int H, int W,
+                  void* stream) {
+    return mtn_conv1_fwd_run(x_nchw, w, y, stats, dtype, B, H, W, (hipStream_t)stream);
+}
+
+int mtn_conv1_wgrad_partial_rows(int B, int H, int W) {
+    return mtn_reduce_rows_needed(mtn_conv1_wgrad_blocks((long)B * (H / 2) * (W / 2)));
+}
+
+int mtn_conv1_wgrad(const float* x_nchw, const void* dy, float* dw, float* partial, int dtype, int B, int H,
+                    int W, void* stream) {
+    return mtn_conv1_wgrad_run(x_nchw, dy, dw, partial, dtype, B, H, W, (hipStream_t)stream);
+}
+
+int mtn_slab_rows(int rows) { return mtn_reduce_rows_needed(rows); }
+
+int mtn_bn_finalize(float* stats, int tiles, int C, long long count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                    float eps, float* scale_shift, float* mean_rstd, void* stream) {
+    return mtn_bn_finalize_run(stats, tiles, C, (long)count, gamma, beta, running_mean, running_var,
+                               num_batches_tracked, momentum, eps, scale_shift, mean_rstd, (hipStream_t)stream);
+}
+
+int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void* res, int ldres, void* out,
+                   int ldo, int dtype, int M, int C, int act, void* stream) {
+    return mtn_bn_act_fwd_run(y, ldy, scale_shift, res, ldres, out, ldo, dtype, M, C, act, (hipStream_t)stream);
+}
+
+int mtn_bn_bwd_partial_rows(int M) { return mtn_reduce_rows_needed(mtn_bn_bwd_blocks(M)); }
+
+int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
+                   const float* scale_shift, const float* mean_rstd, float* partial, float* coef,
+                   float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
+                   const void* extra, int ldextra, int dtype, int M, int C, int act, void* stream) {
+    BnBwdArgs a{};
+    a.dout = dout; a.lddo = lddo; a.y = y; a.ldy = ldy; a.res = res; a.ldr = ldres;
+    a.scale_shift = scale_shift; a.mean_rstd = mean_rstd; a.partial = partial; a.coef = coef;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.lddy = lddy; a.dres = dres; a.lddres = lddres;
+    a.extra = extra; a.ldextra = ldextra; a.M = M; a.C = C; a.act = act;
+    return mtn_bn_bwd_run(a, dtype, (hipStream_t)stream);
+}
+
+int mtn_debug_set(int key, int value) {
+    if (key == 1) { mtn_wgrad_set_tr16(value); return MTN_OK; }
+    mtn_set_error("debug_set: unknown key %d", key);
+    return MTN_ERR_BAD_ARG;
+}
+
 }  // extern "C"

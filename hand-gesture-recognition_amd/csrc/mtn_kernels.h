@@ -27,3 +27,47 @@ struct IgemmArgs {
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_igemm_tiles_m(int M, int N);
+
+struct WgradArgs {
+    const void* dY; int lddy;     // [M][lddy] output-pixel gradients
+    const void* X; int ldx;       // NHWC input of the forward conv
+    float* partial;               // [splits][N][K] f32 workspace
+    float* dW;                    // [N][Cin][KH][KW] f32 (reference OIHW layout)
+    int B, H, W, Cin, OH, OW, KH, KW, stride, pad;
+    int M, N, K;
+    int splits, rows_per_split;
+};
+int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
+int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);
+void mtn_wgrad_set_tr16(int on);
+
+struct BnBwdArgs {
+    const void* dout; int lddo;       // gradient of the block output act(bn(y) [+res])
+    const void* y; int ldy;           // raw conv output saved by the forward
+    const void* res; int ldr;         // residual input of the forward (or null)
+    const float* scale_shift;         // [2][C] from bn_finalize
+    const float* mean_rstd;           // [2][C]
+    float* partial;                   // [mtn_reduce_rows_needed(mtn_bn_bwd_blocks(M))][2][C]
+    float* coef;                      // [2][C] scratch
+    float* dgamma; float* dbeta;      // [C] parameter gradients (overwritten)
+    void* dy; int lddy;               // gradient of the raw conv output
+    void* dres; int lddres;           // gradient of the residual input (+ extra), or null
+    const void* extra; int ldextra;   // optional tensor added into dres (may alias dres)
+    int M, C, act;
+};
+int mtn_reduce_rows_needed(int rows);
+int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float* gamma, const float* beta,
+                        float* rmean, float* rvar, long long* nbt, float momentum, float eps, float* scale_shift,
+                        float* mean_rstd, hipStream_t stream);
+int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res, int ldr, void* out, int ldo, int dtype,
+                       int M, int C, int act, hipStream_t stream);
+int mtn_bn_bwd_blocks(int M);
+int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream);
+int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream);
+
+int mtn_conv1_tiles(long M);
+int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int dtype, int B, int H, int W,
+                      hipStream_t stream);
+int mtn_conv1_wgrad_blocks(long M);
+int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partial, int dtype, int B, int H, int W,
+                        hipStream_t stream);

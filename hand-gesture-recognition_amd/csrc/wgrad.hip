@@ -1,0 +1,254 @@
+// wgrad.hip -- weight gradients of Conv2d / Linear on MFMA, reduction over the pixel axis.
+//
+//   dW[n][tap][ci] = sum_m dY[m][n] * X(m; tap, ci)        m = (b, oy, ox) output pixels
+//
+// (autograd of model/gelan.py:37-45, model/multitasknet.py:13, model/transformer.py:34-37,56-58.)
+// This is a "TN" GEMM: both operands are stored pixel-major (NHWC), the reduction index m is the
+// slow axis of both.  A workgroup owns a BN x BC tile of dW for ONE tap (n0.., ci0..) and one
+// slice of the pixel axis (split-M); per step it stages BMR pixels of dY[:, n-tile] and of the
+// tap-shifted X[:, ci-tile] into LDS as loaded (pixel-major, 16-byte coalesced) and reads the
+// MFMA operands DOWN the pixel axis: in bf16 with ds_read_b64_tr_b16 (hardware transpose read,
+// cdna_hip_programming.md T10), in f32 one element per lane.
+// Partial tiles go to a [split][N][K] f32 slab; wgrad_reduce sums the splits in order
+// (deterministic, no float atomics) and writes the gradient in the reference's OIHW layout.
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+constexpr int PADB = 16;      // LDS row padding in bytes
+
+// operand fragment read down the reduction (row) axis of a [rows][pitch] LDS tile;
+// base points at [k0][col0]; lane gets rows k0 + koff.., column col0 + (lane & 15).
+template <class T, bool TR> struct ColFrag;
+template <bool TR> struct ColFrag<float, TR> {
+    static __device__ __forceinline__ float load(const float* base, int pitch, int lane) {
+        return base[(lane >> 4) * pitch + (lane & 15)];
+    }
+};
+template <> struct ColFrag<bf16_t, false> {
+    static __device__ __forceinline__ bf16x8_t load(const bf16_t* base, int pitch, int lane) {
+        bf16x8_t f;
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + (8 * (lane >> 4)) * pitch + (lane & 15);
+        unsigned short v[8];
+        MTN_UNROLL for (int j = 0; j < 8; ++j) v[j] = p[j * pitch];
+#ifdef MTN_EMU
+        MTN_UNROLL for (int j = 0; j < 8; ++j) f[j] = v[j];
+#else
+        MTN_UNROLL for (int j = 0; j < 8; ++j) f[j] = __builtin_bit_cast(__bf16, v[j]);
+#endif
+        return f;
+    }
+};
+template <> struct ColFrag<bf16_t, true> {
+    // two transposed 4x16 block reads: rows 8g..8g+3 and 8g+4..8g+7 (g = lane>>4); lane 4q+p of
+    // the group addresses row q, columns 4p..4p+3 and receives column (lane&15) of the 4 rows.
+    static __device__ __forceinline__ bf16x8_t load(const bf16_t* base, int pitch, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        const bf16_t* p0 = base + (8 * g + (i >> 2)) * pitch + 4 * (i & 3);
+        const bf16_t* p1 = p0 + 4 * pitch;
+        bf16x8_t f;
+#ifdef MTN_EMU
+        emu::u16x4 a = emu::ds_read_tr16_b64(p0), b = emu::ds_read_tr16_b64(p1);
+        MTN_UNROLL for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+#else
+        // (the v4i16 form + per-element bit_cast is mis-lowered by hipcc 7.2: use v4bf16 + shuffle)
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
+        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p0));
+        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p1));
+        f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+        return f;
+    }
+};
+
+template <class T, int BN, int BC, int WGM, int WGN, bool TR>
+__global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BMR = 128 / (int)sizeof(T);          // pixels per step: 64 bf16 / 32 f32
+    constexpr int KI = Mma<T>::KI;
+    constexpr int PY = BN + PADB / (int)sizeof(T);     // LDS pitches (elements)
+    constexpr int PX = BC + PADB / (int)sizeof(T);
+    constexpr int CPRY = BN / VEC, CPRX = BC / VEC;    // 16-byte chunks per row
+    constexpr int RY = BMR * CPRY / NT, RX = BMR * CPRX / NT;
+    constexpr int WM = BN / WGM, WN = BC / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    static_assert(BMR * CPRY % NT == 0 && BMR * CPRX % NT == 0, "loader mapping");
+
+    MTN_DYN_SMEM(smem);
+    T* const sY = reinterpret_cast<T*>(smem);          // [2][BMR][PY]
+    T* const sX = sY + 2 * BMR * PY;                   // [2][BMR][PX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+
+    // blockIdx.x = (n-tile, k-tile) fastest, blockIdx.y = split
+    const int tiles_n = p.N / BN;
+    const int tile_n = blockIdx.x % tiles_n, tile_k = blockIdx.x / tiles_n;
+    const int n0 = tile_n * BN;
+    const int kcol0 = tile_k * BC;                     // column in [0, K)
+    const int tap = kcol0 / p.Cin, c0 = kcol0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int split = blockIdx.y;
+    const long m_begin = (long)split * p.rows_per_split;
+    long m_end = m_begin + p.rows_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int steps = (int)((m_end - m_begin + BMR - 1) / BMR);
+
+    const T* __restrict__ gY = reinterpret_cast<const T*>(p.dY);
+    const T* __restrict__ gX = reinterpret_cast<const T*>(p.X);
+    const int ohw = p.OH * p.OW;
+
+    // per-thread loader rows
+    int yrow[RY], ycc[RY];
+    MTN_UNROLL for (int i = 0; i < RY; ++i) { const int c = tid + i * NT; yrow[i] = c / CPRY; ycc[i] = c % CPRY; }
+    int xrow[RX], xcc[RX], xb[RX], xrem[RX];
+    MTN_UNROLL for (int i = 0; i < RX; ++i) {
+        const int c = tid + i * NT; xrow[i] = c / CPRX; xcc[i] = c % CPRX;
+        const long m = m_begin + xrow[i];
+        xb[i] = (int)(m / ohw); xrem[i] = (int)(m - (long)xb[i] * ohw);
+    }
+
+    chunk16 ry[RY], rx[RX];
+    auto load_tiles = [&](int st) {
+        const long mb = m_begin + (long)st * BMR;
+        MTN_UNROLL for (int i = 0; i < RY; ++i) {
+            const long m = mb + yrow[i];
+            ry[i] = (m < m_end) ? *reinterpret_cast<const chunk16*>(gY + m * p.lddy + n0 + ycc[i] * VEC) : zero_chunk();
+        }
+        MTN_UNROLL for (int i = 0; i < RX; ++i) {
+            const long m = mb + xrow[i];
+            const int oy = xrem[i] / p.OW, ox = xrem[i] - oy * p.OW;
+            const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+            const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            rx[i] = ok ? *reinterpret_cast<const chunk16*>(gX + ((long)(xb[i] * p.H + iy) * p.W + ix) * p.ldx + c0 + xcc[i] * VEC)
+                       : zero_chunk();
+            xrem[i] += BMR;                                  // advance this row to the next step
+            while (xrem[i] >= ohw) { xrem[i] -= ohw; ++xb[i]; }
+        }
+    };
+    auto store_tiles = [&](int stage) {
+        T* y = sY + stage * BMR * PY;
+        T* x = sX + stage * BMR * PX;
+        MTN_UNROLL for (int i = 0; i < RY; ++i) *reinterpret_cast<chunk16*>(y + yrow[i] * PY + ycc[i] * VEC) = ry[i];
+        MTN_UNROLL for (int i = 0; i < RX; ++i) *reinterpret_cast<chunk16*>(x + xrow[i] * PX + xcc[i] * VEC) = rx[i];
+    };
+
+    f32x4_t acc[FM][FN];
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
+
+    if (steps > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < steps) load_tiles(st + 1);
+        const T* y = sY + cur * BMR * PY + wm * WM;
+        const T* x = sX + cur * BMR * PX + wn * WN;
+        MTN_UNROLL for (int ks = 0; ks < BMR / KI; ++ks) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFrag<T, TR>::load(y + ks * KI * PY + i * 16, PY, lane);
+            MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = ColFrag<T, TR>::load(x + ks * KI * PX + j * 16, PX, lane);
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        }
+        if (st + 1 < steps) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial tile -> slab[split][n][k]   (row = n, 16 consecutive k per 16 lanes)
+    float* __restrict__ out = p.partial + (long)split * p.N * p.K;
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j)
+            MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * WM + i * 16 + 4 * (lane >> 4) + r;
+                const int k = kcol0 + wn * WN + j * 16 + (lane & 15);
+                out[(long)n * p.K + k] = acc[i][j][r];
+            }
+}
+
+// dW_oihw[o][ci][kh][kw] = sum_s partial[s][o][(kh*KW+kw)*Cin + ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int splits, int N, int K, int Cin, int taps) {
+    const long total = (long)N * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < splits; ++q) s += partial[(long)q * total + idx];
+        const int n = (int)(idx / K), k = (int)(idx - (long)n * K);
+        const int tap = k / Cin, ci = k - tap * Cin;
+        dw[((long)n * Cin + ci) * taps + tap] = s;
+    }
+}
+
+template <class T, int BN, int BC, int WGM, int WGN, bool TR>
+int launch_wgrad(const WgradArgs& p, hipStream_t stream) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int BMR = 128 / (int)sizeof(T);
+    constexpr size_t lds = 2 * (size_t)BMR * ((BN + BC) * sizeof(T) + 2 * PADB);
+#ifndef MTN_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BN, BC, WGM, WGN, TR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+#endif
+    const int tiles = (p.N / BN) * (p.K / BC);
+    MTN_LAUNCH((wgrad_kernel<T, BN, BC, WGM, WGN, TR>), dim3(tiles, p.splits), dim3(NT), lds, stream, p);
+    return mtn_check_launch("wgrad");
+}
+
+}  // namespace
+
+static int g_use_tr16 = 1;
+void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
+
+static bool big_tile(int N, int Cin) { return N % 128 == 0 && Cin % 128 == 0; }
+
+// pixels per split: multiple of the step size, >= ~4096 rows, but enough splits to fill the chip
+int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split) {
+    const int bmr = dtype == MTN_BF16 ? 64 : 32;
+    const int t = big_tile(N, Cin) ? 128 : 64;
+    const long tiles = (long)(N / t) * (K / t);
+    long want = (M + 4095) / 4096;
+    const long fill = (1024 + tiles - 1) / tiles;
+    if (want < fill) want = fill;
+    long rps = (M + want - 1) / want;
+    rps = (rps + bmr - 1) / bmr * bmr;
+    if (rps < bmr) rps = bmr;
+    *rows_per_split = (int)rps;
+    return (int)((M + rps - 1) / rps);
+}
+
+int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
+    WgradArgs p = p0;
+    const int bmr = dtype == MTN_BF16 ? 64 : 32;
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "wgrad: bad dtype %d", dtype);
+    MTN_REQUIRE(p.N % 64 == 0 && p.Cin % 64 == 0, "wgrad: N=%d and Cin=%d must be multiples of 64", p.N, p.Cin);
+    MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "wgrad: K mismatch");
+    MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "wgrad: M mismatch");
+    MTN_REQUIRE(p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M,
+                "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
+    MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
+    int rc;
+    if (big_tile(p.N, p.Cin)) {
+        if (dtype == MTN_BF16) rc = g_use_tr16 ? launch_wgrad<bf16_t, 128, 128, 2, 2, true>(p, stream)
+                                               : launch_wgrad<bf16_t, 128, 128, 2, 2, false>(p, stream);
+        else rc = launch_wgrad<float, 128, 128, 2, 2, false>(p, stream);
+    } else {
+        if (dtype == MTN_BF16) rc = g_use_tr16 ? launch_wgrad<bf16_t, 64, 64, 2, 2, true>(p, stream)
+                                               : launch_wgrad<bf16_t, 64, 64, 2, 2, false>(p, stream);
+        else rc = launch_wgrad<float, 64, 64, 2, 2, false>(p, stream);
+    }
+    if (rc) return rc;
+    const long total = (long)p.N * p.K;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    MTN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p.partial, p.dW, p.splits, p.N, p.K,
+               p.Cin, p.KH * p.KW);
+    return mtn_check_launch("wgrad_reduce");
+}

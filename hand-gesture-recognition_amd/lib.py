@@ -20,9 +20,26 @@ _PROTOS = {
     "mtn_conv_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_linear_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_conv_wgrad_workspace_bytes": [_i] * 8,
+    "mtn_conv_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mtn_linear_wgrad_workspace_bytes": [_i] * 4,
+    "mtn_linear_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
+    "mtn_conv1_stats_tiles": [_i, _i, _i],
+    "mtn_conv1_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mtn_conv1_wgrad_partial_rows": [_i, _i, _i],
+    "mtn_conv1_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mtn_slab_rows": [_i],
+    "mtn_bn_finalize": [_vp, _i, _i, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp],
+    "mtn_bn_act_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_bn_bwd_partial_rows": [_i],
+    "mtn_bn_act_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                       _i, _i, _i, _i, _vp],
+    "mtn_debug_set": [_i, _i],
 }
-_RESTYPES = {}
-_STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles"}   # return a value, not a status
+_RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}
+_STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_wgrad_workspace_bytes",
+                "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
+                "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows"}   # return a value, not a status
 
 _lib = None
 _lib_path = None

@@ -72,3 +72,97 @@ def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None):
     rp, ldr = _rows(res) if res is not None else (0, 0)
     lib.call("mtn_linear_fwd", xp, ldx, w.data_ptr(), _p(bias), act, ap, lda, rp, ldr, op, ldo,
              dtype_code(x), M, N, K, _stream(x))
+
+
+def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride):
+    return lib.call("mtn_conv_wgrad_workspace_bytes", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
+
+
+def conv_wgrad(x, dy, dw, workspace, ksize, stride):
+    """x [B,H,W,Cin], dy [B,OH,OW,Cout] -> dw f32 [Cout,Cin,k,k] (overwritten)."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    xp, ldx = _rows(x)
+    dyp, lddy = _rows(dy)
+    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    lib.call("mtn_conv_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
+             workspace.numel() * workspace.element_size(), dtype_code(x), B, H, W, Cin, Cout,
+             ksize, stride, _stream(x))
+
+
+def linear_wgrad_workspace_bytes(dtype, M, N, K):
+    return lib.call("mtn_linear_wgrad_workspace_bytes", _DT[dtype], M, N, K)
+
+
+def linear_wgrad(x, dy, dw, workspace):
+    """dw[N,K] = dy[M,N]^T @ x[M,K] (f32, overwritten)."""
+    K, N = x.shape[-1], dy.shape[-1]
+    M = x.numel() // K
+    xp, ldx = _rows(x)
+    dyp, lddy = _rows(dy)
+    lib.call("mtn_linear_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
+             workspace.numel() * workspace.element_size(), dtype_code(x), M, N, K, _stream(x))
+
+
+def slab_rows(rows):
+    return lib.call("mtn_slab_rows", rows)
+
+
+def bn_finalize(stats, tiles, count, gamma, beta, running_mean, running_var, nbt, scale_shift,
+                mean_rstd, momentum=0.1, eps=1e-5):
+    C = gamma.numel()
+    lib.call("mtn_bn_finalize", stats.data_ptr(), tiles, C, count, gamma.data_ptr(), beta.data_ptr(),
+             _p(running_mean), _p(running_var), _p(nbt), momentum, eps, scale_shift.data_ptr(),
+             mean_rstd.data_ptr(), _stream(stats))
+
+
+def bn_act_fwd(y, scale_shift, out, act, res=None):
+    C = y.shape[-1]
+    M = y.numel() // C
+    yp, ldy = _rows(y)
+    op, ldo = _rows(out)
+    rp, ldr = _rows(res) if res is not None else (0, 0)
+    lib.call("mtn_bn_act_fwd", yp, ldy, scale_shift.data_ptr(), rp, ldr, op, ldo, dtype_code(y),
+             M, C, act, _stream(y))
+
+
+def bn_bwd_partial_rows(M):
+    return lib.call("mtn_bn_bwd_partial_rows", M)
+
+
+def bn_act_bwd(dout, y, res, scale_shift, mean_rstd, partial, coef, dgamma, dbeta, dy, act,
+               dres=None, extra=None):
+    C = y.shape[-1]
+    M = y.numel() // C
+    dop, lddo = _rows(dout)
+    yp, ldy = _rows(y)
+    rp, ldr = _rows(res) if res is not None else (0, 0)
+    dyp, lddy = _rows(dy)
+    drp, lddr = _rows(dres) if dres is not None else (0, 0)
+    ep, lde = _rows(extra) if extra is not None else (0, 0)
+    lib.call("mtn_bn_act_bwd", dop, lddo, yp, ldy, rp, ldr, scale_shift.data_ptr(),
+             mean_rstd.data_ptr(), partial.data_ptr(), coef.data_ptr(), dgamma.data_ptr(),
+             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, dtype_code(y), M, C, act, _stream(y))
+
+
+def conv1_stats_tiles(B, H, W):
+    return lib.call("mtn_conv1_stats_tiles", B, H, W)
+
+
+def conv1_fwd(x_nchw, w, y, stats):
+    """x f32 [B,3,H,W] (NCHW, as the dataloader delivers it) -> y [B,H/2,W/2,64] raw."""
+    B, _, H, W = x_nchw.shape
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and y.is_contiguous()
+    lib.call("mtn_conv1_fwd", x_nchw.data_ptr(), w.data_ptr(), y.data_ptr(), _p(stats),
+             dtype_code(y), B, H, W, _stream(y))
+
+
+def conv1_wgrad_partial_rows(B, H, W):
+    return lib.call("mtn_conv1_wgrad_partial_rows", B, H, W)
+
+
+def conv1_wgrad(x_nchw, dy, dw, partial):
+    B, _, H, W = x_nchw.shape
+    assert dy.is_contiguous() and dw.is_contiguous()
+    lib.call("mtn_conv1_wgrad", x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), partial.data_ptr(),
+             dtype_code(dy), B, H, W, _stream(dy))

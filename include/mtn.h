@@ -53,11 +53,63 @@ int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
                    const void* res, int ldres, int dtype, int B, int H, int W, int Cin, int Cout,
                    int ksize, int stride, void* stream);
 
+/* Stem Conv(3,64,k3,s2) (model/gelan.py:155): reads the NCHW fp32 image batch directly, writes
+ * the NHWC raw output [B][H/2][W/2][64] + stats[mtn_conv1_stats_tiles][2][64]; w packed [64][3][3][3]
+ * as (co, kh, kw, ci).  The image needs no gradient, so there is no conv1 dgrad. */
+int mtn_conv1_stats_tiles(int B, int H, int W);
+int mtn_conv1_fwd(const float* x_nchw, const void* w, void* y, float* stats, int dtype, int B, int H,
+                  int W, void* stream);
+/* dw f32 [64][3][3][3] OIHW (overwritten); partial: f32 [mtn_conv1_wgrad_partial_rows][1728]. */
+int mtn_conv1_wgrad_partial_rows(int B, int H, int W);
+int mtn_conv1_wgrad(const float* x_nchw, const void* dy, float* dw, float* partial, int dtype, int B,
+                    int H, int W, void* stream);
+
 /* ---- nn.Linear / 1x1 projections  (model/transformer.py:34-37,56-58; multitasknet.py:13) ------
  * out = act(x @ w^T + bias) + res ; w is [N][K]; aux_out (optional) gets the pre-activation. */
 int mtn_linear_fwd(const void* x, int ldx, const void* w, const float* bias, int act,
                    void* aux_out, int ld_aux, const void* res, int ldres, void* out, int ldo,
                    int dtype, int M, int N, int K, void* stream);
+
+/* ---- weight gradients (autograd of the Conv2d / Linear sites above) ----------------------------
+ * dw is written (not accumulated) in the reference layout: Conv2d OIHW [Cout][Cin][k][k],
+ * Linear [N][K].  x is the forward input (NHWC), dy the gradient of the raw conv output. */
+size_t mtn_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                                      int stride);
+int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                   size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                   int stride, void* stream);
+size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
+int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                     size_t ws_bytes, int dtype, int M, int N, int K, void* stream);
+
+/* ---- train-mode BatchNorm2d + SiLU (+ residual)  (model/gelan.py:46,56,78-87) -------------------
+ * Slabs of f32 partial sums ([rows][W]) are reduced in row order by the library; a slab that the
+ * caller allocates for `rows` producer rows must have mtn_slab_rows(rows) rows (scratch tail). */
+int mtn_slab_rows(int rows);
+
+/* stats[tiles][2][C] (from mtn_conv_fwd / mtn_conv1_fwd) -> scale_shift[2][C] = (gamma*rstd,
+ * beta - mean*gamma*rstd), mean_rstd[2][C]; updates running_mean/var (unbiased var, momentum) and
+ * num_batches_tracked (+1) in place when given.  count = B*OH*OW. */
+int mtn_bn_finalize(float* stats, int tiles, int C, long long count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float momentum, float eps, float* scale_shift,
+                    float* mean_rstd, void* stream);
+
+/* out = act(y*scale + shift [+ res]), act in {NONE, SILU}. */
+int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void* res, int ldres,
+                   void* out, int ldo, int dtype, int M, int C, int act, void* stream);
+
+/* Backward of the above + BatchNorm: dout -> dy (gradient of the raw conv output), dgamma, dbeta;
+ * dres (optional) = gradient of the residual input [+ extra].  partial: f32
+ * [mtn_bn_bwd_partial_rows(M)][2][C]; coef: f32 [2][C] scratch. */
+int mtn_bn_bwd_partial_rows(int M);
+int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
+                   const float* scale_shift, const float* mean_rstd, float* partial, float* coef,
+                   float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
+                   const void* extra, int ldextra, int dtype, int M, int C, int act, void* stream);
+
+/* test hook: key 1 = use ds_read_b64_tr_b16 operand reads in wgrad (default 1) */
+int mtn_debug_set(int key, int value);
 
 #ifdef __cplusplus
 }

@@ -103,3 +103,74 @@ def test_linear_bias_gelu_residual(be, dtype):
     be.sync()
     assert rel_err(aux.float(), pre) < tol(dtype)
     assert rel_err(out.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tr16", [0, 1])
+@pytest.mark.parametrize("cfg", [
+    (2, 6, 6, 64, 64, 3, 1),
+    (1, 8, 8, 64, 128, 3, 2),
+    (3, 5, 7, 128, 128, 1, 1),
+    (5, 4, 4, 128, 128, 3, 1),
+])
+def test_conv_wgrad(be, dtype, tr16, cfg):
+    from hand_gesture_recognition_amd import lib
+    if dtype == torch.float32 and tr16 == 0:
+        pytest.skip("tr16 only affects bf16")
+    B, H, W, Cin, Cout, k, s = cfg
+    x = _rand((B, H, W, Cin), dtype, 12)
+    w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    yref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, k // 2)
+    dy = _rand(tuple(yref.permute(0, 2, 3, 1).shape), dtype, 13)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    lib.call("mtn_debug_set", 1, tr16)
+    try:
+        ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, k, s) // 4,
+                         dtype=torch.float32, device=be.device)
+        dw = torch.full((Cout, Cin, k, k), float("nan"), device=be.device)
+        ops.conv_wgrad(x.to(be.device), dy.to(be.device), dw, ws, k, s)
+        be.sync()
+    finally:
+        lib.call("mtn_debug_set", 1, 1)
+    assert rel_err(dw, w.grad) < tol(dtype, 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_wgrad_large_m(be, dtype):
+    M, K, N = 300, 256, 64
+    x, dy = _rand((M, K), dtype, 14), _rand((M, N), dtype, 15)
+    ref = dy.float().t() @ x.float()
+    ws = torch.empty(ops.linear_wgrad_workspace_bytes(dtype, M, N, K) // 4, device=be.device)
+    dw = torch.empty((N, K), device=be.device)
+    ops.linear_wgrad(x.to(be.device), dy.to(be.device), dw, ws)
+    be.sync()
+    assert rel_err(dw, ref) < tol(dtype, 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 16, 16), (3, 12, 20), (5, 32, 32)])
+def test_conv1_fwd_wgrad(be, dtype, cfg):
+    B, H, W = cfg
+    x = _rand((B, 3, H, W), torch.float32, 20)
+    w = torch.nn.Parameter(_rand((64, 3, 3, 3), torch.float32, 21) / 27 ** 0.5)
+    wq = w.detach().to(dtype).float().requires_grad_(True)
+    ref = F.conv2d(x, wq, None, 2, 1)
+    dy = _rand((B, H // 2, W // 2, 64), dtype, 22)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    d = be.device
+    y = torch.empty((B, H // 2, W // 2, 64), dtype=dtype, device=d)
+    tiles = ops.conv1_stats_tiles(B, H, W)
+    stats = torch.full((ops.slab_rows(tiles), 2, 64), float("nan"), device=d)
+    xd = x.to(d)
+    ops.conv1_fwd(xd, pack_krsc(w.detach(), dtype).to(d), y, stats)
+    be.sync()
+    assert rel_err(y.float(), ref.permute(0, 2, 3, 1)) < tol(dtype, 1e-4, 1e-2)
+    yf = y.float().cpu().reshape(-1, 64)
+    st = stats[:tiles].cpu().sum(0)
+    assert float((st[0] - yf.sum(0)).abs().max()) < 1e-3 * max(1.0, float(yf.sum(0).abs().max()))
+    assert rel_err(st[1], (yf * yf).sum(0)) < 1e-4
+    part = torch.empty(ops.conv1_wgrad_partial_rows(B, H, W), 64 * 27, device=d)
+    dw = torch.empty((64, 3, 3, 3), device=d)
+    ops.conv1_wgrad(xd, dy.to(d), dw, part)
+    be.sync()
+    assert rel_err(dw, wq.grad) < tol(dtype, 1e-4, 1e-2)

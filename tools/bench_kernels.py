@@ -64,6 +64,20 @@ def main():
             dx = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
             t = timeit(lambda: ops.conv_dgrad(dy, wt, dx, None, k, s))
             print(f"conv_dgrad.{name:6s} M={B*H*W:8d} N={Cin:4d} K={k*k*Cout:5d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s (useful)  {by/t/1e9:7.0f} GB/s")
+    for name, H, W, Cin, Cout, k, s in convs:
+        if a.filter and a.filter not in "conv_wgrad." + name:
+            continue
+        OH, OW = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        M = B * OH * OW
+        x = torch.randn(B, H, W, Cin, device=dev).to(dt)
+        dy = torch.randn(B, OH, OW, Cout, device=dev).to(dt)
+        dw = torch.empty(Cout, Cin, k, k, device=dev)
+        wsb = ops.conv_wgrad_workspace_bytes(dt, B, H, W, Cin, Cout, k, s)
+        ws = torch.empty(wsb // 4, device=dev)
+        t = timeit(lambda: ops.conv_wgrad(x, dy, dw, ws, k, s))
+        fl = 2.0 * M * Cout * k * k * Cin
+        by = (x.numel() + dy.numel()) * esz
+        print(f"conv_wgrad.{name:6s} M={M:8d} N={Cout:4d} K={k*k*Cin:5d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s  ws={wsb/1e6:.0f}MB")
     # ViT linears: M = B*145
     M = B * 145
     for name, K, N in (("qkv", 256, 768), ("out", 256, 256)):
