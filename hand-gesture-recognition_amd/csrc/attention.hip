@@ -1,0 +1,389 @@
+// attention.hip -- multi-head self-attention core of the ViT encoder on MFMA, forward + backward.
+//
+// Reference: Attention.forward (model/transformer.py:62-77), heads = 8, head_dim = 32,
+//   dots = q k^T * 32^-0.5 ; attn = softmax(dots) ; out = attn v ; merge heads.
+// Inputs are read straight out of the fused qkv projection [B*N][768] = (q | k | v) x (h d)
+// and the output is written head-merged [B*N][256], so none of the reference's four
+// rearranges (transformer.py:66-67,74) exists as a pass.  One workgroup = one (batch, head);
+// N = 145 (192^2) or 577 (384^2) tokens: K and V of the head live in LDS for the whole kernel.
+//
+// Orientation (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"):
+// the score tile is computed TRANSPOSED, S^T[key][query] = K Q^T, so a lane owns ONE query
+// column: softmax needs 2 shuffles per row, and the probability accumulators are directly the
+// B operand of the next product that sums over keys (O^T = V^T P^T forward, dQ^T = K^T dS^T
+// backward) -- P never goes through LDS or HBM.  The products that sum over queries (dV, dK)
+// use the untransposed S = Q K^T in a second kernel whose LDS holds Q and dO.  Operands that
+// must be read down the reduction axis of a row-major LDS tile use ds_read_b64_tr_b16.
+// head_dim = 32 is exactly one bf16 MFMA K step.  Backward recomputes P from the saved
+// log-sum-exp (flash style); only the last layer's probabilities are written (they are the
+// module's attnmap output, transformer.py:96,152).
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+constexpr int HD = 32;                       // head_dim (model/multitasknet.py:21)
+template <class T> struct Lay { static constexpr int PITCH = HD + 16 / (int)sizeof(T); };
+
+// ---- operand over the head_dim axis of one row (A: [row][k], B: [k][col]) ----------------------
+template <class T> struct RowOp;
+template <> struct RowOp<bf16_t> {
+    bf16x8_t f;
+    __device__ __forceinline__ void load(const bf16_t* row, bool valid, int g) {
+        chunk16 c = valid ? *reinterpret_cast<const chunk16*>(row + 8 * g) : zero_chunk();
+#ifdef MTN_EMU
+        std::memcpy(&f, &c, 16);
+#else
+        f = __builtin_bit_cast(bf16x8_t, c);
+#endif
+    }
+};
+template <> struct RowOp<float> {
+    float f[8];
+    __device__ __forceinline__ void load(const float* row, bool valid, int g) {
+        MTN_UNROLL for (int ks = 0; ks < 8; ++ks) f[ks] = valid ? row[ks * 4 + g] : 0.f;
+    }
+};
+__device__ __forceinline__ f32x4_t mma32(const RowOp<bf16_t>& a, const RowOp<bf16_t>& b, f32x4_t c) {
+    return Mma<bf16_t>::mma(a.f, b.f, c);
+}
+__device__ __forceinline__ f32x4_t mma32(const RowOp<float>& a, const RowOp<float>& b, f32x4_t c) {
+    MTN_UNROLL for (int ks = 0; ks < 8; ++ks) c = Mma<float>::mma(a.f[ks], b.f[ks], c);
+    return c;
+}
+template <class T> __device__ __forceinline__ float dot_rowops(const RowOp<T>& a, const RowOp<T>& b);
+template <> __device__ __forceinline__ float dot_rowops<float>(const RowOp<float>& a, const RowOp<float>& b) {
+    float s = 0.f;
+    MTN_UNROLL for (int i = 0; i < 8; ++i) s += a.f[i] * b.f[i];
+    return s;
+}
+template <> __device__ __forceinline__ float dot_rowops<bf16_t>(const RowOp<bf16_t>& a, const RowOp<bf16_t>& b) {
+    float s = 0.f;
+    MTN_UNROLL for (int i = 0; i < 8; ++i) {
+#ifdef MTN_EMU
+        s += emu::bf2f(a.f[i]) * emu::bf2f(b.f[i]);
+#else
+        s += (float)a.f[i] * (float)b.f[i];
+#endif
+    }
+    return s;
+}
+
+// out[c][n] += sum over the 32 rows r of col[r][c0 + c] * X[r][n], where X (32 x 16) is given as
+// two accumulator tiles t0 (rows 0..15) and t1 (rows 16..31) in MFMA C/D layout (row 4g+j, col
+// lane&15) and `col` points at [row0][c0] of a row-major LDS tile.  The k order inside the step
+// is the accumulators' own: slot (g, j) <-> row 4g+j (j<4) / 16+4g+(j-4).
+__device__ __forceinline__ f32x4_t acc_mma(const bf16_t* col, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const bf16_t* p0 = col + (4 * g + (i >> 2)) * pitch + 4 * (i & 3);
+    const bf16_t* p1 = p0 + 16 * pitch;
+    bf16x8_t a, b;
+#ifdef MTN_EMU
+    emu::u16x4 u = emu::ds_read_tr16_b64(p0), v = emu::ds_read_tr16_b64(p1);
+    MTN_UNROLL for (int j = 0; j < 4; ++j) { a[j] = u[j]; a[4 + j] = v[j]; b[j] = f2bf(t0[j]).v; b[4 + j] = f2bf(t1[j]).v; }
+#else
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
+    const bf16x4_t u = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p0));
+    const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p1));
+    a = __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7);
+    MTN_UNROLL for (int j = 0; j < 4; ++j) { b[j] = (__bf16)t0[j]; b[4 + j] = (__bf16)t1[j]; }
+#endif
+    return Mma<bf16_t>::mma(a, b, out);
+}
+__device__ __forceinline__ f32x4_t acc_mma(const float* col, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    MTN_UNROLL for (int j = 0; j < 4; ++j) out = Mma<float>::mma(col[(4 * g + j) * pitch + i], t0[j], out);
+    MTN_UNROLL for (int j = 0; j < 4; ++j) out = Mma<float>::mma(col[(16 + 4 * g + j) * pitch + i], t1[j], out);
+    return out;
+}
+
+// stage rows [0, NP) x 32 of one head (column offset `coff` of a [B*N][ld] tensor) into LDS, zero padded
+template <class T>
+__device__ __forceinline__ void stage_head(T* dst, const T* __restrict__ src, int ld, int coff, long row0, int N, int NP) {
+    constexpr int VEC = 16 / (int)sizeof(T), CPR = HD / VEC, PITCH = Lay<T>::PITCH;
+    for (int i = threadIdx.x; i < NP * CPR; i += blockDim.x) {
+        const int r = i / CPR, c = (i - r * CPR) * VEC;
+        *reinterpret_cast<chunk16*>(dst + r * PITCH + c) =
+            (r < N) ? *reinterpret_cast<const chunk16*>(src + (row0 + r) * ld + coff + c) : zero_chunk();
+    }
+}
+
+template <class T> __device__ __forceinline__ void store4(T* dst, f32x4_t v);
+template <> __device__ __forceinline__ void store4<float>(float* dst, f32x4_t v) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, f32x4_t v) {
+    uint2 u = make_uint2((unsigned)f2bf(v[0]).v | ((unsigned)f2bf(v[1]).v << 16),
+                         (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16));
+    *reinterpret_cast<uint2*>(dst) = u;
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+template <class T, int MAXT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
+                                                       float* __restrict__ attn, int N, int H, float scale) {
+    constexpr int PITCH = Lay<T>::PITCH;
+    MTN_DYN_SMEM(smem);
+    const int NP = (N + 31) & ~31, nkt = NP / 16, nqt = (N + 15) / 16;
+    T* sK = reinterpret_cast<T*>(smem);
+    T* sV = sK + NP * PITCH;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int ld = 3 * H * HD;
+    const long row0 = (long)b * N;
+    stage_head<T>(sK, qkv, ld, H * HD + h * HD, row0, N, NP);
+    stage_head<T>(sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    for (int qt = wid; qt < nqt; qt += 4) {
+        const int q = qt * 16 + li;
+        const bool qok = q < N;
+        RowOp<T> qf;
+        qf.load(qkv + (row0 + (qok ? q : 0)) * ld + h * HD, qok, g);
+        f32x4_t s[MAXT];
+        float mx = -3.0e38f;
+        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {
+                RowOp<T> kf;
+                kf.load(sK + (kt * 16 + li) * PITCH, true, g);
+                s[kt] = mma32(kf, qf, zero4());
+                MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                    const bool kok = kt * 16 + 4 * g + r < N;
+                    s[kt][r] = kok ? s[kt][r] * scale : -3.0e38f;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {
+                MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                    const bool kok = kt * 16 + 4 * g + r < N;
+                    const float e = kok ? __expf(s[kt][r] - mx) : 0.f;
+                    s[kt][r] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (qok && g == 0) lse[(long)bh * N + q] = mx + __logf(sum);
+        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {
+                MTN_UNROLL for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+                if (attn && qok) {
+                    float* ap = attn + ((long)bh * N + q) * N + kt * 16 + 4 * g;
+                    MTN_UNROLL for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + 4 * g + r < N) ap[r] = s[kt][r];
+                }
+            }
+        }
+        f32x4_t o0 = zero4(), o1 = zero4();
+        MTN_UNROLL for (int pr = 0; pr < MAXT / 2; ++pr) {
+            if (2 * pr < nkt) {
+                o0 = acc_mma(sV + pr * 32 * PITCH, PITCH, s[2 * pr], s[2 * pr + 1], o0, lane);
+                o1 = acc_mma(sV + pr * 32 * PITCH + 16, PITCH, s[2 * pr], s[2 * pr + 1], o1, lane);
+            }
+        }
+        if (qok) {      // O^T tiles: rows d = dt*16 + 4g + r, column q
+            T* op = out + (row0 + q) * (H * HD) + h * HD + 4 * g;
+            store4<T>(op, o0);
+            store4<T>(op + 16, o1);
+        }
+    }
+}
+
+// ---- backward 1: dQ (sums over keys) and delta = rowsum(dO * O) ----------------------------------
+template <class T, int MAXT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                          const T* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, T* __restrict__ dqkv, int N, int H,
+                                                          float scale) {
+    constexpr int PITCH = Lay<T>::PITCH;
+    MTN_DYN_SMEM(smem);
+    const int NP = (N + 31) & ~31, nkt = NP / 16, nqt = (N + 15) / 16;
+    T* sK = reinterpret_cast<T*>(smem);
+    T* sV = sK + NP * PITCH;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int ld = 3 * H * HD, ldo = H * HD;
+    const long row0 = (long)b * N;
+    stage_head<T>(sK, qkv, ld, H * HD + h * HD, row0, N, NP);
+    stage_head<T>(sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    for (int qt = wid; qt < nqt; qt += 4) {
+        const int q = qt * 16 + li;
+        const bool qok = q < N;
+        const long qr = row0 + (qok ? q : 0);
+        RowOp<T> qf, dof, of;
+        qf.load(qkv + qr * ld + h * HD, qok, g);
+        dof.load(dout + qr * ldo + h * HD, qok, g);
+        of.load(o + qr * ldo + h * HD, qok, g);
+        float dl = dot_rowops<T>(dof, of);
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        const float lq = qok ? lse[(long)bh * N + q] : 0.f;
+        if (qok && g == 0) delta[(long)bh * N + q] = dl;
+        f32x4_t ds[MAXT];
+        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {
+                RowOp<T> kf, vf;
+                kf.load(sK + (kt * 16 + li) * PITCH, true, g);
+                vf.load(sV + (kt * 16 + li) * PITCH, true, g);
+                const f32x4_t s = mma32(kf, qf, zero4());
+                const f32x4_t dp = mma32(vf, dof, zero4());
+                MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                    const bool ok = qok && (kt * 16 + 4 * g + r < N);
+                    const float p = ok ? __expf(s[r] * scale - lq) : 0.f;
+                    ds[kt][r] = p * (dp[r] - dl) * scale;
+                }
+            }
+        }
+        f32x4_t d0 = zero4(), d1 = zero4();
+        MTN_UNROLL for (int pr = 0; pr < MAXT / 2; ++pr) {
+            if (2 * pr < nkt) {
+                d0 = acc_mma(sK + pr * 32 * PITCH, PITCH, ds[2 * pr], ds[2 * pr + 1], d0, lane);
+                d1 = acc_mma(sK + pr * 32 * PITCH + 16, PITCH, ds[2 * pr], ds[2 * pr + 1], d1, lane);
+            }
+        }
+        if (qok) {
+            T* dp = dqkv + (row0 + q) * ld + h * HD + 4 * g;
+            store4<T>(dp, d0);
+            store4<T>(dp + 16, d1);
+        }
+    }
+}
+
+// ---- backward 2: dK, dV (sum over queries); LDS holds Q and dO of the head ------------------------
+template <class T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           T* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int PITCH = Lay<T>::PITCH;
+    MTN_DYN_SMEM(smem);
+    const int NP = (N + 31) & ~31, nkt = (N + 15) / 16, nqp = NP / 32;
+    T* sQ = reinterpret_cast<T*>(smem);
+    T* sD = sQ + NP * PITCH;
+    float* sL = reinterpret_cast<float*>(sD + NP * PITCH);      // lse[NP]
+    float* sDl = sL + NP;                                       // delta[NP]
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int ld = 3 * H * HD, ldo = H * HD;
+    const long row0 = (long)b * N;
+    stage_head<T>(sQ, qkv, ld, h * HD, row0, N, NP);
+    stage_head<T>(sD, dout, ldo, h * HD, row0, N, NP);
+    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        sL[i] = i < N ? lse[(long)bh * N + i] : 0.f;
+        sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    for (int kt = wid; kt < nkt; kt += 4) {
+        const int key = kt * 16 + li;
+        const bool kok = key < N;
+        const long kr = row0 + (kok ? key : 0);
+        RowOp<T> kf, vf;                                  // B operands K^T, V^T: [k = d][col = key]
+        kf.load(qkv + kr * ld + H * HD + h * HD, kok, g);
+        vf.load(qkv + kr * ld + 2 * H * HD + h * HD, kok, g);
+        f32x4_t dk0 = zero4(), dk1 = zero4(), dv0 = zero4(), dv1 = zero4();
+        for (int qp = 0; qp < nqp; ++qp) {
+            f32x4_t p[2], ds[2];
+            MTN_UNROLL for (int hf = 0; hf < 2; ++hf) {
+                const int qb = qp * 32 + hf * 16;
+                RowOp<T> qa, da;                          // A operands: rows = queries
+                qa.load(sQ + (qb + li) * PITCH, true, g);
+                da.load(sD + (qb + li) * PITCH, true, g);
+                const f32x4_t s = mma32(qa, kf, zero4());       // S[q = qb+4g+r][key]
+                const f32x4_t dp = mma32(da, vf, zero4());      // dP[q][key]
+                MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                    const int q = qb + 4 * g + r;
+                    const bool ok = kok && q < N;
+                    const float pv = ok ? __expf(s[r] * scale - sL[q]) : 0.f;
+                    p[hf][r] = pv;
+                    ds[hf][r] = pv * (dp[r] - sDl[q]) * scale;
+                }
+            }
+            dv0 = acc_mma(sD + qp * 32 * PITCH, PITCH, p[0], p[1], dv0, lane);          // dV^T += dO^T P
+            dv1 = acc_mma(sD + qp * 32 * PITCH + 16, PITCH, p[0], p[1], dv1, lane);
+            dk0 = acc_mma(sQ + qp * 32 * PITCH, PITCH, ds[0], ds[1], dk0, lane);        // dK^T += Q^T dS
+            dk1 = acc_mma(sQ + qp * 32 * PITCH + 16, PITCH, ds[0], ds[1], dk1, lane);
+        }
+        if (kok) {
+            T* dkp = dqkv + (row0 + key) * ld + H * HD + h * HD + 4 * g;
+            T* dvp = dqkv + (row0 + key) * ld + 2 * H * HD + h * HD + 4 * g;
+            store4<T>(dkp, dk0); store4<T>(dkp + 16, dk1);
+            store4<T>(dvp, dv0); store4<T>(dvp + 16, dv1);
+        }
+    }
+}
+
+template <class K>
+void set_max_lds(K kern, size_t lds) {
+#ifndef MTN_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
+}
+
+template <class T>
+int attn_fwd_t(const AttnArgs& a, hipStream_t stream) {
+    const int NP = (a.N + 31) & ~31;
+    const size_t lds = 2 * (size_t)NP * Lay<T>::PITCH * sizeof(T);
+    const dim3 grid(a.B * a.H), block(256);
+    if (NP / 16 <= 10) {
+        set_max_lds(attn_fwd_kernel<T, 10>, lds);
+        MTN_LAUNCH((attn_fwd_kernel<T, 10>), grid, block, lds, stream, (const T*)a.qkv, (T*)a.out, a.lse, a.attn, a.N, a.H, a.scale);
+    } else {
+        set_max_lds(attn_fwd_kernel<T, 38>, lds);
+        MTN_LAUNCH((attn_fwd_kernel<T, 38>), grid, block, lds, stream, (const T*)a.qkv, (T*)a.out, a.lse, a.attn, a.N, a.H, a.scale);
+    }
+    return mtn_check_launch("attn_fwd");
+}
+
+template <class T>
+int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
+    const int NP = (a.N + 31) & ~31;
+    const size_t lds = 2 * (size_t)NP * Lay<T>::PITCH * sizeof(T);
+    const dim3 grid(a.B * a.H), block(256);
+    if (NP / 16 <= 10) {
+        set_max_lds(attn_bwd_dq_kernel<T, 10>, lds);
+        MTN_LAUNCH((attn_bwd_dq_kernel<T, 10>), grid, block, lds, stream, (const T*)a.qkv, (const T*)a.out, (const T*)a.dout,
+                   a.lse, a.delta, (T*)a.dqkv, a.N, a.H, a.scale);
+    } else {
+        set_max_lds(attn_bwd_dq_kernel<T, 38>, lds);
+        MTN_LAUNCH((attn_bwd_dq_kernel<T, 38>), grid, block, lds, stream, (const T*)a.qkv, (const T*)a.out, (const T*)a.dout,
+                   a.lse, a.delta, (T*)a.dqkv, a.N, a.H, a.scale);
+    }
+    int rc = mtn_check_launch("attn_bwd_dq");
+    if (rc) return rc;
+    const size_t lds2 = lds + 2 * (size_t)NP * sizeof(float);
+    set_max_lds(attn_bwd_dkv_kernel<T>, lds2);
+    MTN_LAUNCH((attn_bwd_dkv_kernel<T>), grid, block, lds2, stream, (const T*)a.qkv, (const T*)a.dout, a.lse, a.delta,
+               (T*)a.dqkv, a.N, a.H, a.scale);
+    return mtn_check_launch("attn_bwd_dkv");
+}
+
+int check_attn(const AttnArgs& a, int dtype) {
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "attention: bad dtype");
+    MTN_REQUIRE(a.B > 0 && a.H > 0 && a.N > 0 && a.D == HD, "attention: head_dim must be %d (got %d)", HD, a.D);
+    const int NP = (a.N + 31) & ~31;
+    MTN_REQUIRE(NP / 16 <= 38, "attention: N=%d exceeds the register-resident limit 608", a.N);
+    const size_t lds = 2 * (size_t)NP * (HD * (dtype == MTN_BF16 ? 2 : 4) + 16) + 2 * (size_t)NP * 4;
+    MTN_REQUIRE(lds <= 160 * 1024, "attention: N=%d does not fit LDS in this dtype (%zu bytes)", a.N, lds);
+    return MTN_OK;
+}
+
+}  // namespace
+
+int mtn_attn_fwd_run(const AttnArgs& a, int dtype, hipStream_t stream) {
+    int rc = check_attn(a, dtype);
+    if (rc) return rc;
+    return dtype == MTN_BF16 ? attn_fwd_t<bf16_t>(a, stream) : attn_fwd_t<float>(a, stream);
+}
+
+int mtn_attn_bwd_run(const AttnArgs& a, int dtype, hipStream_t stream) {
+    int rc = check_attn(a, dtype);
+    if (rc) return rc;
+    return dtype == MTN_BF16 ? attn_bwd_t<bf16_t>(a, stream) : attn_bwd_t<float>(a, stream);
+}

@@ -162,6 +162,76 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
     return mtn_bn_bwd_run(a, dtype, (hipStream_t)stream);
 }
 
+int mtn_tokens_fwd(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B, int P, void* stream) {
+    return mtn_tokens_fwd_run(feat, pos, cls, tok, dtype, B, P, (hipStream_t)stream);
+}
+int mtn_tokens_bwd(const void* dtok, void* dfeat, float* dcls, int dtype, int B, int P, void* stream) {
+    return mtn_tokens_bwd_run(dtok, dfeat, dcls, dtype, B, P, (hipStream_t)stream);
+}
+int mtn_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean_rstd,
+                      int dtype, int M, float eps, void* stream) {
+    return mtn_ln_fwd_run(x, ldx, gamma, beta, y, ldy, mean_rstd, dtype, M, eps, (hipStream_t)stream);
+}
+int mtn_rowslab_rows(int M) { return mtn_reduce_rows_needed(mtn_rowslab_blocks(M)); }
+int mtn_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma,
+                      const void* dres, int lddres, void* dx, int lddx, float* partial, float* dgamma_dbeta, int dtype,
+                      int M, void* stream) {
+    return mtn_ln_bwd_run(dy, lddy, x, ldx, mean_rstd, gamma, dres, lddres, dx, lddx, partial, dgamma_dbeta, dtype, M,
+                          (hipStream_t)stream);
+}
+int mtn_gelu_bwd(const void* dh, const void* a, void* da, int dtype, long long n, void* stream) {
+    return mtn_gelu_bwd_run(dh, a, da, dtype, (long)n, (hipStream_t)stream);
+}
+int mtn_bias_grad(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, void* stream) {
+    return mtn_bias_grad_run(dy, lddy, partial, dbias, dtype, M, (hipStream_t)stream);
+}
+int mtn_attention_fwd(const void* qkv, void* out, float* lse, float* attn, int dtype, int B, int N, int H, int D,
+                      float scale, void* stream) {
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.lse = lse; a.attn = attn; a.B = B; a.N = N; a.H = H; a.D = D; a.scale = scale;
+    return mtn_attn_fwd_run(a, dtype, (hipStream_t)stream);
+}
+int mtn_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                      int dtype, int B, int N, int H, int D, float scale, void* stream) {
+    AttnArgs a{};
+    a.qkv = qkv; a.out = const_cast<void*>(out); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta;
+    a.dqkv = dqkv; a.B = B; a.N = N; a.H = H; a.D = D; a.scale = scale;
+    return mtn_attn_bwd_run(a, dtype, (hipStream_t)stream);
+}
+int mtn_cls_head_fwd(const void* tok, long long tok_stride, const float* ln_w, const float* ln_b, const float* W,
+                     const float* bias, float* logits, float* xhat, float* mean_rstd, int dtype, int B, int C, float eps,
+                     void* stream) {
+    return mtn_cls_head_fwd_run(tok, (long)tok_stride, ln_w, ln_b, W, bias, logits, xhat, mean_rstd, dtype, B, C, eps,
+                                (hipStream_t)stream);
+}
+int mtn_cls_head_bwd(const float* dlogits, const float* W, const float* ln_w, const float* ln_b, const float* xhat,
+                     const float* mean_rstd, void* dtok, long long tok_stride, float* dW, float* dbias, float* dln_w_b,
+                     float* partial, int dtype, int B, int C, void* stream) {
+    return mtn_cls_head_bwd_run(dlogits, W, ln_w, ln_b, xhat, mean_rstd, dtok, (long)tok_stride, dW, dbias, dln_w_b, partial,
+                                dtype, B, C, (hipStream_t)stream);
+}
+int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
+                      void* stream) {
+    return mtn_pose_fwd_run(tok, W, bias, hm, dtype, B, h, w, J, (hipStream_t)stream);
+}
+int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW, float* dbias, float* slab,
+                      int dtype, int B, int h, int w, int J, void* stream) {
+    return mtn_pose_bwd_run(tok, W, dhm, dtok, dW, dbias, slab, dtype, B, h, w, J, (hipStream_t)stream);
+}
+int mtn_loss_partial_len(long long n) { return mtn_loss_blocks((long)n); }
+int mtn_loss_fwd_bwd(const float* logits, const long long* label, const float* hm, const float* target,
+                     const float* target_weight, float* dlogits, float* dhm, float* partial, float* losses, int B, int C,
+                     int J, int HW, float ce_weight, void* stream) {
+    return mtn_loss_run(logits, label, hm, target, target_weight, dlogits, dhm, partial, losses, B, C, J, HW, ce_weight,
+                        (hipStream_t)stream);
+}
+int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, float* state, void* stream) {
+    return mtn_adamw_run(p, g, m, v, (long)n, state, (hipStream_t)stream);
+}
+int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, void* stream) {
+    return mtn_pack_run(src, dst, desc, ntensors, max_elems, dtype, (hipStream_t)stream);
+}
+
 int mtn_debug_set(int key, int value) {
     if (key == 1) { mtn_wgrad_set_tr16(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);

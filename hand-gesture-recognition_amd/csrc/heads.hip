@@ -1,0 +1,305 @@
+// heads.hip -- pose head and the fused training loss.
+//
+// Pose head (model/transformer.py:118-127,146-150): tokens[:,1:] viewed as [B,256,h,w] ->
+//   F.interpolate(x4, bilinear, align_corners=True) -> ReLU -> Conv2d(256 -> J, 1x1, bias) -> NCHW fp32.
+// The 16x larger upsampled tensor is never materialised: a workgroup interpolates + ReLUs an 8x8
+// output tile into LDS and contracts it with the J x 256 weight matrix from LDS.  The backward
+// recomputes the upsampled features per (image, channel chunk), accumulates the bilinear scatter
+// in an LDS-resident token-gradient tile and writes dW partials to a per-image slab.
+//
+// Loss (libs/loss.py:4-40, train.py:63-64,75): total = 0.001 * CrossEntropy(mean) + JointsMSE,
+// JointsMSE == 0.5 * mean_{b,j,p} (w_bj (p - t))^2; the kernel emits the three scalars and both
+// gradients (dlogits, dheatmap) in one pass.
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+constexpr int DIM = 256;
+constexpr int MAXJ = 24;
+
+// PyTorch's align_corners=True source index: src = dst * (in-1)/(out-1), in fp32
+struct Lerp { int i0, i1; float w1; };
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
+    const float r = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float s = r * (float)dst;
+    Lerp l;
+    l.i0 = (int)s;
+    if (l.i0 > in - 1) l.i0 = in - 1;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = s - (float)l.i0;
+    return l;
+}
+
+constexpr int TP = 8;                 // output tile edge
+constexpr int UP = DIM + 4;           // LDS pitch of the feature tile (floats)
+
+template <class T>
+__global__ __launch_bounds__(256) void pose_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ hm, int h, int w,
+                                                       int J) {
+    MTN_DYN_SMEM(smem);
+    float* sU = reinterpret_cast<float*>(smem);         // [64][UP]
+    float* sW = sU + TP * TP * UP;                      // [J][DIM]
+    const int OH = 4 * h, OW = 4 * w;
+    const int tiles_x = (OW + TP - 1) / TP;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < J * DIM; i += 256) sW[i] = W[i];
+    // phase 1: interpolate + ReLU; thread = (pixel lane, 4 channels)
+    {
+        const int cg = tid & 63, pq = tid >> 6;
+        const T* base = tok + ((long)b * (h * w + 1) + 1) * DIM + cg * 4;
+        for (int px = pq; px < TP * TP; px += 4) {
+            const int oy = ty * TP + px / TP, ox = tx * TP + px % TP;
+            float u[4] = {0.f, 0.f, 0.f, 0.f};
+            if (oy < OH && ox < OW) {
+                const Lerp ly = lerp_coord(oy, h, OH), lx = lerp_coord(ox, w, OW);
+                {
+                    float t0[4], t1[4], t2[4], t3[4];
+                    const T* p00 = base + (long)(ly.i0 * w + lx.i0) * DIM;
+                    const T* p01 = base + (long)(ly.i0 * w + lx.i1) * DIM;
+                    const T* p10 = base + (long)(ly.i1 * w + lx.i0) * DIM;
+                    const T* p11 = base + (long)(ly.i1 * w + lx.i1) * DIM;
+                    MTN_UNROLL for (int e = 0; e < 4; ++e) {
+                        t0[e] = to_f<T>(p00[e]); t1[e] = to_f<T>(p01[e]); t2[e] = to_f<T>(p10[e]); t3[e] = to_f<T>(p11[e]);
+                    }
+                    const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
+                    MTN_UNROLL for (int e = 0; e < 4; ++e) {
+                        const float v = wy0 * (wx0 * t0[e] + lx.w1 * t1[e]) + ly.w1 * (wx0 * t2[e] + lx.w1 * t3[e]);
+                        u[e] = v > 0.f ? v : 0.f;
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(sU + px * UP + cg * 4) = make_float4(u[0], u[1], u[2], u[3]);
+        }
+    }
+    __syncthreads();
+    // phase 2: thread = (pixel, joint group); joints jg, jg+4, ...
+    const int px = tid & 63, jg = tid >> 6;
+    float acc[MAXJ / 4];
+    MTN_UNROLL for (int q = 0; q < MAXJ / 4; ++q) acc[q] = 0.f;
+    for (int c = 0; c < DIM; c += 4) {
+        const float4 uv = *reinterpret_cast<const float4*>(sU + px * UP + c);
+        MTN_UNROLL for (int q = 0; q < MAXJ / 4; ++q) {
+            const int j = jg + 4 * q;
+            if (j < J) {
+                const float4 wv = *reinterpret_cast<const float4*>(sW + j * DIM + c);
+                acc[q] += uv.x * wv.x + uv.y * wv.y + uv.z * wv.z + uv.w * wv.w;
+            }
+        }
+    }
+    const int oy = ty * TP + px / TP, ox = tx * TP + px % TP;
+    if (oy < OH && ox < OW) {
+        MTN_UNROLL for (int q = 0; q < MAXJ / 4; ++q) {
+            const int j = jg + 4 * q;
+            if (j < J) hm[(((long)b * J + j) * OH + oy) * OW + ox] = acc[q] + bias[j];
+        }
+    }
+}
+
+// block = (channel chunk of CC, image b); threads = CC channels x (256/CC) pixel lanes
+template <class T, int CC>
+__global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok, const float* __restrict__ W,
+                                                       const float* __restrict__ dhm, T* __restrict__ dtok,
+                                                       float* __restrict__ dWslab, int h, int w, int J) {
+    constexpr int PL = 256 / CC;
+    MTN_DYN_SMEM(smem);
+    const int hw = h * w, OH = 4 * h, OW = 4 * w;
+    float* sS = reinterpret_cast<float*>(smem);         // source tokens [hw][CC]
+    float* sG = sS + hw * CC;                           // token-gradient accumulator [hw][CC]
+    float* sR = sG + hw * CC;                           // [PL][J][CC] dW reduction
+    const int b = blockIdx.y, c0 = blockIdx.x * CC;
+    const int c = threadIdx.x % CC, pl = threadIdx.x / CC;
+    const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + c0;
+    for (int i = threadIdx.x; i < hw * CC; i += 256) {
+        const int p = i / CC, cc = i - p * CC;
+        sS[i] = to_f<T>(base[(long)p * DIM + cc]);
+        sG[i] = 0.f;
+    }
+    float wj[MAXJ], dw[MAXJ];
+    MTN_UNROLL for (int j = 0; j < MAXJ; ++j) { wj[j] = j < J ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; }
+    __syncthreads();
+    const float* dh = dhm + (long)b * J * OH * OW;
+    for (int px = pl; px < OH * OW; px += PL) {
+        const int oy = px / OW, ox = px - oy * OW;
+        const Lerp ly = lerp_coord(oy, h, OH), lx = lerp_coord(ox, w, OW);
+        const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
+        const int i00 = (ly.i0 * w + lx.i0) * CC + c, i01 = (ly.i0 * w + lx.i1) * CC + c;
+        const int i10 = (ly.i1 * w + lx.i0) * CC + c, i11 = (ly.i1 * w + lx.i1) * CC + c;
+        const float v = wy0 * (wx0 * sS[i00] + lx.w1 * sS[i01]) + ly.w1 * (wx0 * sS[i10] + lx.w1 * sS[i11]);
+        const float u = v > 0.f ? v : 0.f;
+        float g = 0.f;
+        MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
+            if (j < J) {
+                const float d = dh[(long)j * OH * OW + px];
+                g += d * wj[j];
+                dw[j] += d * u;
+            }
+        }
+        if (v > 0.f) {
+            atomicAdd(&sG[i00], g * wy0 * wx0);
+            atomicAdd(&sG[i01], g * wy0 * lx.w1);
+            atomicAdd(&sG[i10], g * ly.w1 * wx0);
+            atomicAdd(&sG[i11], g * ly.w1 * lx.w1);
+        }
+    }
+    MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
+        if (j < J) sR[(pl * J + j) * CC + c] = dw[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * CC; i += 256) {
+        const int p = i / CC, cc = i - p * CC;
+        dtok[((long)b * (hw + 1) + 1 + p) * DIM + c0 + cc] = from_f<T>(sG[i]);
+    }
+    for (int i = threadIdx.x; i < J * CC; i += 256) {
+        const int j = i / CC, cc = i - j * CC;
+        float s = 0.f;
+        for (int q = 0; q < PL; ++q) s += sR[(q * J + j) * CC + cc];
+        dWslab[((long)b * J + j) * DIM + c0 + cc] = s;
+    }
+}
+
+// dbias[j] = sum_{b,p} dhm[b][j][p]     (one block per joint)
+__global__ __launch_bounds__(256) void pose_bias_grad_kernel(const float* __restrict__ dhm, float* __restrict__ dbias, int B,
+                                                             int J, int HW) {
+    __shared__ float red[256];
+    const int j = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int p = threadIdx.x; p < HW; p += 256) s += dhm[((long)b * J + j) * HW + p];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbias[j] = red[0];
+}
+
+// ---- loss ------------------------------------------------------------------------------------------
+// dhm = w^2 (p - t) / n ; partial[block] = sum 0.5 (w (p - t))^2 / n,  n = B*J*HW
+__global__ __launch_bounds__(256) void jmse_kernel(const float* __restrict__ hm, const float* __restrict__ tgt,
+                                                   const float* __restrict__ tw, float* __restrict__ dhm,
+                                                   float* __restrict__ partial, long n, int HW) {
+    __shared__ float red[256];
+    const float inv = 1.0f / (float)n;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float wgt = tw[i / HW];
+        const float d = wgt * (hm[i] - tgt[i]);
+        s += 0.5f * d * d;
+        if (dhm) dhm[i] = wgt * d * inv;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] * inv;
+}
+
+// single block: cross entropy over the batch + final sum of the heat-map partials
+// losses = (total, 0.001*CE, JMSE); dlogits = ce_weight/B (softmax - onehot)
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                        float* __restrict__ dlogits, const float* __restrict__ partial,
+                                                        int nparts, float* __restrict__ losses, int B, int C,
+                                                        float ce_weight) {
+    __shared__ float red[2][256];
+    float ce = 0.f, jm = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* l = logits + (long)b * C;
+        float mx = l[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += __expf(l[c] - mx);
+        const int y = (int)label[b];
+        ce += mx + __logf(sum) - l[y];
+        if (dlogits) {
+            const float k = ce_weight / (float)B, inv = 1.0f / sum;
+            for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = k * (__expf(l[c] - mx) * inv - (c == y ? 1.f : 0.f));
+        }
+    }
+    for (int i = threadIdx.x; i < nparts; i += 256) jm += partial[i];
+    red[0][threadIdx.x] = ce;
+    red[1][threadIdx.x] = jm;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float cl = ce_weight * red[0][0] / (float)B;
+        losses[1] = cl;
+        losses[2] = red[1][0];
+        losses[0] = cl + red[1][0];
+    }
+}
+
+}  // namespace
+
+int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
+                     hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_fwd: bad sizes (J=%d, max %d)", J, MAXJ);
+    const int OH = 4 * h, OW = 4 * w;
+    const dim3 grid(mtn_cdiv(OH, TP) * mtn_cdiv(OW, TP), B);
+    const size_t lds = (size_t)(TP * TP * UP + J * DIM) * sizeof(float);
+#ifndef MTN_EMU
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+#endif
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(pose_fwd_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)tok, W, bias, hm, h, w, J);
+    else
+        MTN_LAUNCH(pose_fwd_kernel<float>, grid, dim3(256), lds, stream, (const float*)tok, W, bias, hm, h, w, J);
+    return mtn_check_launch("pose_fwd");
+}
+
+template <class T, int CC>
+static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, void* dtok, float* slab, int B, int h, int w, int J,
+                           hipStream_t stream) {
+    const size_t lds = ((size_t)2 * h * w * CC + (size_t)(256 / CC) * J * CC) * sizeof(float);
+    MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS", h, w);
+#ifndef MTN_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    MTN_LAUNCH((pose_bwd_kernel<T, CC>), dim3(DIM / CC, B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
+    return mtn_check_launch("pose_bwd");
+}
+
+int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW, float* dbias, float* slab,
+                     int dtype, int B, int h, int w, int J, hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
+    int rc;
+    const bool small = (size_t)h * w <= 256;
+    if (dtype == MTN_BF16) rc = small ? pose_bwd_launch<bf16_t, 64>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
+                                      : pose_bwd_launch<bf16_t, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    else rc = small ? pose_bwd_launch<float, 64>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
+                    : pose_bwd_launch<float, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    if (rc) return rc;
+    MTN_LAUNCH(pose_bias_grad_kernel, dim3(J), dim3(256), 0, stream, dhm, dbias, B, J, 16 * h * w);
+    rc = mtn_check_launch("pose_bias_grad");
+    if (rc) return rc;
+    return mtn_colsum_run(slab, B, J * DIM, dW, stream);
+}
+
+int mtn_loss_blocks(long n) {
+    long b = (n + 1023) / 1024;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int mtn_loss_run(const float* logits, const long long* label, const float* hm, const float* tgt, const float* tw,
+                 float* dlogits, float* dhm, float* partial, float* losses, int B, int C, int J, int HW, float ce_weight,
+                 hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && C > 0 && J > 0 && HW > 0, "loss: bad sizes");
+    const long n = (long)B * J * HW;
+    const int blocks = mtn_loss_blocks(n);
+    MTN_LAUNCH(jmse_kernel, dim3(blocks), dim3(256), 0, stream, hm, tgt, tw, dhm, partial, n, HW);
+    MTN_LAUNCH(ce_finish_kernel, dim3(1), dim3(256), 0, stream, logits, label, dlogits, partial, blocks, losses, B, C, ce_weight);
+    return mtn_check_launch("loss");
+}

@@ -71,3 +71,41 @@ int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int 
 int mtn_conv1_wgrad_blocks(long M);
 int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partial, int dtype, int B, int H, int W,
                         hipStream_t stream);
+
+struct AttnArgs {
+    const void* qkv;      // [B*N][3*H*D]  (q | k | v) x (h d)
+    void* out;            // [B*N][H*D] attention output (forward: written; backward: read)
+    const void* dout;     // [B*N][H*D] gradient of out (backward)
+    float* lse;           // [B*H][N] log-sum-exp of the scaled scores
+    float* delta;         // [B*H][N] rowsum(dout*out) scratch (backward)
+    float* attn;          // [B][H][N][N] probabilities or null (forward)
+    void* dqkv;           // [B*N][3*H*D] (backward)
+    int B, N, H, D;
+    float scale;
+};
+int mtn_attn_fwd_run(const AttnArgs& a, int dtype, hipStream_t stream);
+int mtn_attn_bwd_run(const AttnArgs& a, int dtype, hipStream_t stream);
+
+int mtn_tokens_fwd_run(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B, int P, hipStream_t stream);
+int mtn_tokens_bwd_run(const void* dtok, void* dfeat, float* dcls, int dtype, int B, int P, hipStream_t stream);
+int mtn_ln_fwd_run(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean_rstd, int dtype,
+                   int M, float eps, hipStream_t stream);
+int mtn_rowslab_blocks(int M);
+int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma, const void* dres,
+                   int lddres, void* dx, int lddx, float* partial, float* dgamma_dbeta, int dtype, int M, hipStream_t stream);
+int mtn_gelu_bwd_run(const void* dh, const void* a, void* da, int dtype, long n, hipStream_t stream);
+int mtn_bias_grad_run(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, hipStream_t stream);
+int mtn_cls_head_fwd_run(const void* tok, long tok_stride, const float* lg, const float* lb, const float* W, const float* bias,
+                         float* logits, float* xhat, float* mean_rstd, int dtype, int B, int C, float eps, hipStream_t stream);
+int mtn_cls_head_bwd_run(const float* dlogits, const float* W, const float* lg, const float* lb, const float* xhat,
+                         const float* mean_rstd, void* dtok, long tok_stride, float* dW, float* dbias, float* dlg_dlb,
+                         float* partial, int dtype, int B, int C, hipStream_t stream);
+int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
+                     hipStream_t stream);
+int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW, float* dbias, float* slab,
+                     int dtype, int B, int h, int w, int J, hipStream_t stream);
+int mtn_loss_blocks(long n);
+int mtn_loss_run(const float* logits, const long long* label, const float* hm, const float* tgt, const float* tw, float* dlogits,
+                 float* dhm, float* partial, float* losses, int B, int C, int J, int HW, float ce_weight, hipStream_t stream);
+int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* state, hipStream_t stream);
+int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream);

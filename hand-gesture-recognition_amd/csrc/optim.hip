@@ -1,0 +1,82 @@
+// optim.hip -- flat fused AdamW over all 7.4 M parameters and the per-step weight repack.
+//
+// Reference: torch.optim.AdamW(model.parameters(), lr) with defaults betas (0.9, 0.999), eps 1e-8,
+// weight_decay 0.01 on EVERY tensor (train.py:50-51).  Parameters, gradients and both moments
+// live in four flat fp32 buffers (the nn.Parameters are views), so one launch replaces the
+// reference's 114 per-tensor updates.  Step-dependent scalars (step count, bias corrections,
+// lr, gradient scale 1/world_size) are read from a small device-resident state block so the
+// whole step can be replayed from a hipGraph.
+//
+// state f32[16]: 0 lr, 1 beta1, 2 beta2, 3 eps, 4 weight_decay, 5 step, 6 bias_corr1,
+//                7 bias_corr2, 8 grad_scale
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+__global__ void adamw_tick_kernel(float* __restrict__ st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float t = st[5] + 1.0f;
+        st[5] = t;
+        st[6] = 1.0f - powf(st[1], t);
+        st[7] = 1.0f - powf(st[2], t);
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n4, const float* __restrict__ st) {
+    const float lr = st[0], b1 = st[1], b2 = st[2], eps = st[3], wd = st[4], bc1 = st[6], bc2 = st[7], gs = st[8];
+    const float step_size = lr / bc1, rs2 = rsqrtf(bc2), decay = 1.0f - lr * wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+        MTN_UNROLL for (int e = 0; e < 4; ++e) {
+            const float gr = ga[e] * gs;
+            pa[e] *= decay;
+            ma[e] = b1 * ma[e] + (1.0f - b1) * gr;
+            va[e] = b2 * va[e] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(va[e]) * rs2 + eps;
+            pa[e] -= step_size * (ma[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+// desc[t] = {src_off, dst_off, O, I, taps, mode}; mode 0: dst[o][tap][i], mode 1: dst[i][tap][o]; src is OIHW [o][i][tap]
+template <class T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, const int* __restrict__ desc) {
+    const int* d = desc + blockIdx.y * 6;
+    const int so = d[0], dof = d[1], O = d[2], I = d[3], taps = d[4], mode = d[5];
+    const int n = O * I * taps;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        int o, i, tap;
+        if (mode == 0) { i = idx % I; tap = (idx / I) % taps; o = idx / (I * taps); }
+        else { o = idx % O; tap = (idx / O) % taps; i = idx / (O * taps); }
+        dst[dof + idx] = from_f<T>(src[so + (o * I + i) * taps + tap]);
+    }
+}
+
+}  // namespace
+
+int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* state, hipStream_t stream) {
+    MTN_REQUIRE(n > 0 && n % 4 == 0, "adamw: n=%ld must be a positive multiple of 4", n);
+    MTN_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "adamw: buffers must be 16-byte aligned");
+    MTN_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), 0, stream, state);
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    MTN_LAUNCH(adamw_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, m, v, n4, (const float*)state);
+    return mtn_check_launch("adamw");
+}
+
+int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream) {
+    MTN_REQUIRE(ntensors > 0 && max_elems > 0, "pack: bad sizes");
+    int bx = (max_elems + 255) / 256;
+    if (bx > 256) bx = 256;
+    if (dtype == MTN_BF16) MTN_LAUNCH(pack_kernel<bf16_t>, dim3(bx, ntensors), dim3(256), 0, stream, src, (bf16_t*)dst, desc);
+    else MTN_LAUNCH(pack_kernel<float>, dim3(bx, ntensors), dim3(256), 0, stream, src, (float*)dst, desc);
+    return mtn_check_launch("pack");
+}

@@ -1,0 +1,365 @@
+// vit.hip -- the row-wise / elementwise kernels of the ViT encoder and its heads (dim = 256):
+//   token assembly        (model/transformer.py:132-139)  rearrange + pos-emb add + cls concat
+//   LayerNorm fwd / bwd   (model/transformer.py:33,54,114; eps 1e-5, biased variance)
+//   GELU backward         (model/transformer.py:35, exact erf form)
+//   classification head   (model/transformer.py:113-116,142-144)  LN + Linear(256 -> classes)
+// All are HBM-bound: one wave per 256-wide row, 8/16-byte lanes, fp32 math, ordered slab sums
+// for the parameter gradients.
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+constexpr int DIM = 256;
+constexpr int EPL = DIM / 64;        // elements per lane in a wave-per-row kernel
+
+template <class T> __device__ __forceinline__ void load_row4(const T* p, float* v);
+template <> __device__ __forceinline__ void load_row4<float>(const float* p, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load_row4<bf16_t>(const bf16_t* p, float* v) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    bf16_t a; a.v = (unsigned short)(t.x & 0xffff); v[0] = bf2f(a);
+    a.v = (unsigned short)(t.x >> 16); v[1] = bf2f(a);
+    a.v = (unsigned short)(t.y & 0xffff); v[2] = bf2f(a);
+    a.v = (unsigned short)(t.y >> 16); v[3] = bf2f(a);
+}
+template <class T> __device__ __forceinline__ void store_row4(T* p, const float* v);
+template <> __device__ __forceinline__ void store_row4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, const float* v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)f2bf(v[0]).v | ((unsigned)f2bf(v[1]).v << 16),
+                                              (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16));
+}
+
+// ---- token assembly ------------------------------------------------------------------------------
+// tokens[b][0] = cls ; tokens[b][1+p] = feat[b*P + p] + pos[p]
+template <class T>
+__global__ __launch_bounds__(256) void tokens_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ pos,
+                                                         const float* __restrict__ cls, T* __restrict__ tok, int B, int P) {
+    const int lane = threadIdx.x & 63;
+    const long rows = (long)B * (P + 1);
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const int b = (int)(r / (P + 1)), t = (int)(r - (long)b * (P + 1));
+        float v[EPL];
+        if (t == 0) {
+            MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] = cls[lane * EPL + e];
+        } else {
+            load_row4<T>(feat + ((long)b * P + t - 1) * DIM + lane * EPL, v);
+            MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] += pos[(t - 1) * DIM + lane * EPL + e];
+        }
+        store_row4<T>(tok + r * DIM + lane * EPL, v);
+    }
+}
+// dfeat[b*P+p] = dtok[b][1+p]
+template <class T>
+__global__ __launch_bounds__(256) void tokens_bwd_kernel(const T* __restrict__ dtok, T* __restrict__ dfeat, int B, int P) {
+    const int lane = threadIdx.x & 63;
+    const long rows = (long)B * P;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const int b = (int)(r / P), p = (int)(r - (long)b * P);
+        float v[EPL];
+        load_row4<T>(dtok + ((long)b * (P + 1) + 1 + p) * DIM + lane * EPL, v);
+        store_row4<T>(dfeat + r * DIM + lane * EPL, v);
+    }
+}
+// dcls[c] = sum_b dtok[b][0][c]   (single block; B rows)
+template <class T>
+__global__ __launch_bounds__(256) void cls_grad_kernel(const T* __restrict__ dtok, float* __restrict__ dcls, int B, int P) {
+    const int c = threadIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += to_f<T>(dtok[(long)b * (P + 1) * DIM + c]);
+    dcls[c] = s;
+}
+
+// ---- LayerNorm -----------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y, int ldy,
+                                                     float* __restrict__ mean_rstd, int M, float eps) {
+    const int lane = threadIdx.x & 63;
+    float gm[EPL], bt[EPL];
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) { gm[e] = gamma[lane * EPL + e]; bt[e] = beta[lane * EPL + e]; }
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += (long)gridDim.x * 4) {
+        float v[EPL];
+        load_row4<T>(x + r * ldx + lane * EPL, v);
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DIM);
+        float d = 0.f;
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) { v[e] -= mean; d += v[e] * v[e]; }
+        const float rstd = rsqrtf(wave_sum(d) * (1.0f / DIM) + eps);
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] = v[e] * rstd * gm[e] + bt[e];
+        store_row4<T>(y + r * ldy + lane * EPL, v);
+        if (mean_rstd && lane == 0) { mean_rstd[2 * r] = mean; mean_rstd[2 * r + 1] = rstd; }
+    }
+}
+
+// dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma;
+// partial[block][0][c] = sum dy*xhat (dgamma), partial[block][1][c] = sum dy (dbeta)
+template <class T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                     const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                     const T* __restrict__ dres, int lddres, T* __restrict__ dx, int lddx,
+                                                     float* __restrict__ partial, int M, int rows_per_block) {
+    __shared__ float red[4][2][DIM];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float gm[EPL], sg[EPL], sb[EPL];
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) { gm[e] = gamma[lane * EPL + e]; sg[e] = 0.f; sb[e] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (long r = r0 + w; r < r1; r += 4) {
+        float g[EPL], xv[EPL];
+        load_row4<T>(dy + r * lddy + lane * EPL, g);
+        load_row4<T>(x + r * ldx + lane * EPL, xv);
+        const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
+        float a = 0.f, b = 0.f;
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) {
+            xv[e] = (xv[e] - mean) * rstd;
+            sg[e] += g[e] * xv[e];
+            sb[e] += g[e];
+            g[e] *= gm[e];
+            a += g[e];
+            b += g[e] * xv[e];
+        }
+        a = wave_sum(a) * (1.0f / DIM);
+        b = wave_sum(b) * (1.0f / DIM);
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] = rstd * (g[e] - a - xv[e] * b);
+        if (dres) {
+            float rr[EPL];
+            load_row4<T>(dres + r * lddres + lane * EPL, rr);
+            MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] += rr[e];
+        }
+        store_row4<T>(dx + r * lddx + lane * EPL, g);
+    }
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) { red[w][0][lane * EPL + e] = sg[e]; red[w][1][lane * EPL + e] = sb[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * DIM; i += 256) {
+        const int which = i / DIM, c = i - which * DIM;
+        partial[(long)blockIdx.x * 2 * DIM + i] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+}
+
+// ---- GELU backward: da = dh * gelu'(a) --------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ a, T* __restrict__ da,
+                                                       long nchunks) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        float g[VEC], v[VEC];
+        unpack<T>(reinterpret_cast<const chunk16*>(dh)[i], g);
+        unpack<T>(reinterpret_cast<const chunk16*>(a)[i], v);
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) g[e] *= gelu_grad_(v[e]);
+        reinterpret_cast<chunk16*>(da)[i] = pack<T>(g);
+    }
+}
+
+// column sums of a T tensor: partial[block][c] = sum over the block's rows of x[r][c]  (bias grads)
+template <class T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int ldx, float* __restrict__ partial,
+                                                             int M, int rows_per_block) {
+    __shared__ float red[4][DIM];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float s[EPL];
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) s[e] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (long r = r0 + w; r < r1; r += 4) {
+        float v[EPL];
+        load_row4<T>(x + r * ldx + lane * EPL, v);
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) s[e] += v[e];
+    }
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) red[w][lane * EPL + e] = s[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    partial[(long)blockIdx.x * DIM + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// ---- classification head -------------------------------------------------------------------------
+// one wave per sample: xn = LN(tok[b][0]); logits = xn W^T + bias.  xn and (mean, rstd) are saved.
+template <class T>
+__global__ __launch_bounds__(64) void cls_head_fwd_kernel(const T* __restrict__ tok, long tok_stride, const float* __restrict__ lg,
+                                                          const float* __restrict__ lb, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ logits,
+                                                          float* __restrict__ xn_out, float* __restrict__ mean_rstd, int C,
+                                                          float eps) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    float v[EPL];
+    load_row4<T>(tok + (long)b * tok_stride + lane * EPL, v);
+    const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DIM);
+    float d = 0.f;
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) { v[e] -= mean; d += v[e] * v[e]; }
+    const float rstd = rsqrtf(wave_sum(d) * (1.0f / DIM) + eps);
+    float xh[EPL];
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) {
+        xh[e] = v[e] * rstd;
+        v[e] = xh[e] * lg[lane * EPL + e] + lb[lane * EPL + e];
+        xn_out[(long)b * DIM + lane * EPL + e] = xh[e];          // xhat (pre-affine) for the backward
+    }
+    if (lane == 0) { mean_rstd[2 * b] = mean; mean_rstd[2 * b + 1] = rstd; }
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) s += v[e] * W[c * DIM + lane * EPL + e];
+        s = wave_sum(s);
+        if (lane == 0) logits[(long)b * C + c] = s + bias[c];
+    }
+}
+
+// per sample: dxn = dlogits W; LN backward -> dtok[b][0] (written, not accumulated);
+// partial[b][0][k] = dxn*xhat, partial[b][1][k] = dxn  (LayerNorm affine gradients, summed over b later)
+template <class T>
+__global__ __launch_bounds__(64) void cls_head_bwd_x_kernel(const float* __restrict__ dlogits, const float* __restrict__ W,
+                                                            const float* __restrict__ lg, const float* __restrict__ xhat,
+                                                            const float* __restrict__ mean_rstd, T* __restrict__ dtok,
+                                                            long tok_stride, float* __restrict__ partial, int C) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    float g[EPL], xh[EPL];
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) { g[e] = 0.f; xh[e] = xhat[(long)b * DIM + lane * EPL + e]; }
+    for (int c = 0; c < C; ++c) {
+        const float dl = dlogits[(long)b * C + c];
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] += dl * W[c * DIM + lane * EPL + e];
+    }
+    float a = 0.f, bb = 0.f;
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) {
+        partial[((long)b * 2 + 0) * DIM + lane * EPL + e] = g[e] * xh[e];
+        partial[((long)b * 2 + 1) * DIM + lane * EPL + e] = g[e];
+        g[e] *= lg[lane * EPL + e]; a += g[e]; bb += g[e] * xh[e];
+    }
+    a = wave_sum(a) * (1.0f / DIM);
+    bb = wave_sum(bb) * (1.0f / DIM);
+    const float rstd = mean_rstd[2 * b + 1];
+    MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] = rstd * (g[e] - a - xh[e] * bb);
+    store_row4<T>(dtok + (long)b * tok_stride + lane * EPL, g);
+}
+
+// block c: dW[c][k] = sum_b dl[b][c]*xn[b][k], dbias[c] = sum_b dl[b][c]
+__global__ __launch_bounds__(256) void cls_head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ lg,
+                                                             const float* __restrict__ lb, const float* __restrict__ xhat,
+                                                             float* __restrict__ dW, float* __restrict__ dbias, int B, int C) {
+    const int k = threadIdx.x, c = blockIdx.x;
+    const float gk = lg[k], bk = lb[k];
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float dl = dlogits[(long)b * C + c];
+        s += dl * (xhat[(long)b * DIM + k] * gk + bk);
+        sb += dl;
+    }
+    dW[c * DIM + k] = s;
+    if (k == 0) dbias[c] = sb;
+}
+
+inline int row_grid(long rows) {
+    long b = (rows + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, KERN, ...)                                                   \
+    do {                                                                               \
+        if ((dtype) == MTN_BF16) { MTN_LAUNCH(KERN<bf16_t>, __VA_ARGS__); }            \
+        else { MTN_LAUNCH(KERN<float>, __VA_ARGS__); }                                 \
+    } while (0)
+
+int mtn_tokens_fwd_run(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B, int P,
+                       hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && P > 0, "tokens_fwd: bad sizes");
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(tokens_fwd_kernel<bf16_t>, dim3(row_grid((long)B * (P + 1))), dim3(256), 0, stream, (const bf16_t*)feat, pos, cls, (bf16_t*)tok, B, P);
+    else
+        MTN_LAUNCH(tokens_fwd_kernel<float>, dim3(row_grid((long)B * (P + 1))), dim3(256), 0, stream, (const float*)feat, pos, cls, (float*)tok, B, P);
+    return mtn_check_launch("tokens_fwd");
+}
+
+int mtn_tokens_bwd_run(const void* dtok, void* dfeat, float* dcls, int dtype, int B, int P, hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && P > 0, "tokens_bwd: bad sizes");
+    if (dtype == MTN_BF16) {
+        MTN_LAUNCH(tokens_bwd_kernel<bf16_t>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const bf16_t*)dtok, (bf16_t*)dfeat, B, P);
+        MTN_LAUNCH(cls_grad_kernel<bf16_t>, dim3(1), dim3(256), 0, stream, (const bf16_t*)dtok, dcls, B, P);
+    } else {
+        MTN_LAUNCH(tokens_bwd_kernel<float>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const float*)dtok, (float*)dfeat, B, P);
+        MTN_LAUNCH(cls_grad_kernel<float>, dim3(1), dim3(256), 0, stream, (const float*)dtok, dcls, B, P);
+    }
+    return mtn_check_launch("tokens_bwd");
+}
+
+int mtn_ln_fwd_run(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean_rstd,
+                   int dtype, int M, float eps, hipStream_t stream) {
+    MTN_REQUIRE(M > 0 && ldx % 4 == 0 && ldy % 4 == 0, "ln_fwd: bad sizes");
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(ln_fwd_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean_rstd, M, eps);
+    else
+        MTN_LAUNCH(ln_fwd_kernel<float>, dim3(row_grid(M)), dim3(256), 0, stream, (const float*)x, ldx, gamma, beta, (float*)y, ldy, mean_rstd, M, eps);
+    return mtn_check_launch("ln_fwd");
+}
+
+static const int kLnRows = 64;
+int mtn_rowslab_blocks(int M) { return mtn_cdiv(M, kLnRows); }
+
+int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma,
+                   const void* dres, int lddres, void* dx, int lddx, float* partial, float* dgamma_dbeta, int dtype,
+                   int M, hipStream_t stream) {
+    MTN_REQUIRE(M > 0, "ln_bwd: bad sizes");
+    const int blocks = mtn_rowslab_blocks(M);
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean_rstd,
+                   gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partial, M, kLnRows);
+    else
+        MTN_LAUNCH(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, (const float*)x, ldx, mean_rstd,
+                   gamma, (const float*)dres, lddres, (float*)dx, lddx, partial, M, kLnRows);
+    int rc = mtn_check_launch("ln_bwd");
+    if (rc) return rc;
+    return mtn_colsum_run(partial, blocks, 2 * DIM, dgamma_dbeta, stream);   // [dgamma | dbeta]
+}
+
+int mtn_gelu_bwd_run(const void* dh, const void* a, void* da, int dtype, long n, hipStream_t stream) {
+    const int vec = dtype == MTN_BF16 ? 8 : 4;
+    MTN_REQUIRE(n > 0 && n % vec == 0, "gelu_bwd: n=%ld must be a multiple of %d", n, vec);
+    const long chunks = n / vec;
+    long blocks = (chunks + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(gelu_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)dh, (const bf16_t*)a, (bf16_t*)da, chunks);
+    else
+        MTN_LAUNCH(gelu_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, (const float*)dh, (const float*)a, (float*)da, chunks);
+    return mtn_check_launch("gelu_bwd");
+}
+
+int mtn_bias_grad_run(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, hipStream_t stream) {
+    MTN_REQUIRE(M > 0, "bias_grad: bad sizes");
+    const int blocks = mtn_rowslab_blocks(M);
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(colsum_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, partial, M, kLnRows);
+    else
+        MTN_LAUNCH(colsum_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, partial, M, kLnRows);
+    int rc = mtn_check_launch("bias_grad");
+    if (rc) return rc;
+    return mtn_colsum_run(partial, blocks, DIM, dbias, stream);
+}
+
+int mtn_cls_head_fwd_run(const void* tok, long tok_stride, const float* lg, const float* lb, const float* W,
+                         const float* bias, float* logits, float* xhat, float* mean_rstd, int dtype, int B, int C,
+                         float eps, hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && C > 0, "cls_head_fwd: bad sizes");
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(cls_head_fwd_kernel<bf16_t>, dim3(B), dim3(64), 0, stream, (const bf16_t*)tok, tok_stride, lg, lb, W, bias, logits, xhat, mean_rstd, C, eps);
+    else
+        MTN_LAUNCH(cls_head_fwd_kernel<float>, dim3(B), dim3(64), 0, stream, (const float*)tok, tok_stride, lg, lb, W, bias, logits, xhat, mean_rstd, C, eps);
+    return mtn_check_launch("cls_head_fwd");
+}
+
+int mtn_cls_head_bwd_run(const float* dlogits, const float* W, const float* lg, const float* lb, const float* xhat,
+                         const float* mean_rstd, void* dtok, long tok_stride, float* dW, float* dbias,
+                         float* dlg_dlb, float* partial, int dtype, int B, int C, hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && C > 0, "cls_head_bwd: bad sizes");
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(cls_head_bwd_x_kernel<bf16_t>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (bf16_t*)dtok, tok_stride, partial, C);
+    else
+        MTN_LAUNCH(cls_head_bwd_x_kernel<float>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (float*)dtok, tok_stride, partial, C);
+    MTN_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, stream, dlogits, lg, lb, xhat, dW, dbias, B, C);
+    int rc = mtn_check_launch("cls_head_bwd");
+    if (rc) return rc;
+    return mtn_colsum_run(partial, B, 2 * DIM, dlg_dlb, stream);
+}

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "libmtn_hip.so")
 
-_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
 # name -> argtypes  (restype is int unless listed in _RESTYPES)
 _PROTOS = {
@@ -34,12 +34,30 @@ _PROTOS = {
     "mtn_bn_bwd_partial_rows": [_i],
     "mtn_bn_act_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                        _i, _i, _i, _i, _vp],
+    "mtn_tokens_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_tokens_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_layernorm_fwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _f, _vp],
+    "mtn_rowslab_rows": [_i],
+    "mtn_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
+    "mtn_gelu_bwd": [_vp, _vp, _vp, _i, _ll, _vp],
+    "mtn_bias_grad": [_vp, _i, _vp, _vp, _i, _i, _vp],
+    "mtn_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "mtn_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "mtn_cls_head_fwd": [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "mtn_cls_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_pose_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_pose_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_loss_partial_len": [_ll],
+    "mtn_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "mtn_adamw_step": [_vp, _vp, _vp, _vp, _ll, _vp, _vp],
+    "mtn_pack_weights": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_debug_set": [_i, _i],
 }
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}
 _STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
-                "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows"}   # return a value, not a status
+                "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
+                "mtn_loss_partial_len"}   # return a value, not a status
 
 _lib = None
 _lib_path = None

@@ -166,3 +166,109 @@ def conv1_wgrad(x_nchw, dy, dw, partial):
     assert dy.is_contiguous() and dw.is_contiguous()
     lib.call("mtn_conv1_wgrad", x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), partial.data_ptr(),
              dtype_code(dy), B, H, W, _stream(dy))
+
+
+# ---- ViT encoder --------------------------------------------------------------------------------
+def tokens_fwd(feat, pos, cls, tok):
+    """feat [B*P,256] (+pos f32 [P,256]) and cls f32 [256] -> tok [B,P+1,256]."""
+    B, P1, _ = tok.shape
+    lib.call("mtn_tokens_fwd", feat.data_ptr(), pos.data_ptr(), cls.data_ptr(), tok.data_ptr(),
+             dtype_code(tok), B, P1 - 1, _stream(tok))
+
+
+def tokens_bwd(dtok, dfeat, dcls):
+    B, P1, _ = dtok.shape
+    lib.call("mtn_tokens_bwd", dtok.data_ptr(), dfeat.data_ptr(), dcls.data_ptr(), dtype_code(dtok),
+             B, P1 - 1, _stream(dtok))
+
+
+def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5):
+    xp, ldx = _rows(x)
+    yp, ldy = _rows(y)
+    M = x.numel() // x.shape[-1]
+    lib.call("mtn_layernorm_fwd", xp, ldx, gamma.data_ptr(), beta.data_ptr(), yp, ldy, _p(mean_rstd),
+             dtype_code(x), M, eps, _stream(x))
+
+
+def rowslab_rows(M):
+    return lib.call("mtn_rowslab_rows", M)
+
+
+def layernorm_bwd(dy, x, mean_rstd, gamma, dx, partial, dgamma_dbeta, dres=None):
+    dyp, lddy = _rows(dy)
+    xp, ldx = _rows(x)
+    dxp, lddx = _rows(dx)
+    rp, ldr = _rows(dres) if dres is not None else (0, 0)
+    M = x.numel() // x.shape[-1]
+    lib.call("mtn_layernorm_bwd", dyp, lddy, xp, ldx, mean_rstd.data_ptr(), gamma.data_ptr(), rp, ldr,
+             dxp, lddx, partial.data_ptr(), dgamma_dbeta.data_ptr(), dtype_code(x), M, _stream(x))
+
+
+def gelu_bwd(dh, a, da):
+    assert dh.is_contiguous() and a.is_contiguous() and da.is_contiguous()
+    lib.call("mtn_gelu_bwd", dh.data_ptr(), a.data_ptr(), da.data_ptr(), dtype_code(a), a.numel(), _stream(a))
+
+
+def bias_grad(dy, partial, dbias):
+    dyp, lddy = _rows(dy)
+    M = dy.numel() // dy.shape[-1]
+    lib.call("mtn_bias_grad", dyp, lddy, partial.data_ptr(), dbias.data_ptr(), dtype_code(dy), M, _stream(dy))
+
+
+def attention_fwd(qkv, out, lse, attn, B, N, H, D, scale):
+    lib.call("mtn_attention_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(attn),
+             dtype_code(qkv), B, N, H, D, scale, _stream(qkv))
+
+
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
+    lib.call("mtn_attention_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+             delta.data_ptr(), dqkv.data_ptr(), dtype_code(qkv), B, N, H, D, scale, _stream(qkv))
+
+
+def cls_head_fwd(tok, ln_w, ln_b, W, bias, logits, xhat, mean_rstd, eps=1e-5):
+    B, C = logits.shape
+    lib.call("mtn_cls_head_fwd", tok.data_ptr(), tok.stride(0), ln_w.data_ptr(), ln_b.data_ptr(),
+             W.data_ptr(), bias.data_ptr(), logits.data_ptr(), xhat.data_ptr(), mean_rstd.data_ptr(),
+             dtype_code(tok), B, C, eps, _stream(tok))
+
+
+def cls_head_bwd(dlogits, W, ln_w, ln_b, xhat, mean_rstd, dtok, dW, dbias, dln_w_b, partial):
+    B, C = dlogits.shape
+    lib.call("mtn_cls_head_bwd", dlogits.data_ptr(), W.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+             xhat.data_ptr(), mean_rstd.data_ptr(), dtok.data_ptr(), dtok.stride(0), dW.data_ptr(),
+             dbias.data_ptr(), dln_w_b.data_ptr(), partial.data_ptr(), dtype_code(dtok), B, C, _stream(dtok))
+
+
+def pose_head_fwd(tok, W, bias, hm, h, w):
+    B, J = hm.shape[:2]
+    lib.call("mtn_pose_head_fwd", tok.data_ptr(), W.data_ptr(), bias.data_ptr(), hm.data_ptr(),
+             dtype_code(tok), B, h, w, J, _stream(tok))
+
+
+def pose_head_bwd(tok, W, dhm, dtok, dW, dbias, slab, h, w):
+    B, J = dhm.shape[:2]
+    lib.call("mtn_pose_head_bwd", tok.data_ptr(), W.data_ptr(), dhm.data_ptr(), dtok.data_ptr(),
+             dW.data_ptr(), dbias.data_ptr(), slab.data_ptr(), dtype_code(tok), B, h, w, J, _stream(tok))
+
+
+def loss_partial_len(n):
+    return lib.call("mtn_loss_partial_len", n)
+
+
+def loss_fwd_bwd(logits, label, hm, target, target_weight, dlogits, dhm, partial, losses, ce_weight=0.001):
+    B, C = logits.shape
+    J = hm.shape[1]
+    HW = hm.shape[2] * hm.shape[3]
+    lib.call("mtn_loss_fwd_bwd", logits.data_ptr(), label.data_ptr(), hm.data_ptr(), target.data_ptr(),
+             target_weight.data_ptr(), _p(dlogits), _p(dhm), partial.data_ptr(), losses.data_ptr(),
+             B, C, J, HW, ce_weight, _stream(hm))
+
+
+def adamw_step(p, g, m, v, state):
+    lib.call("mtn_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+             state.data_ptr(), _stream(p))
+
+
+def pack_weights(src, dst, desc, ntensors, max_elems):
+    lib.call("mtn_pack_weights", src.data_ptr(), dst.data_ptr(), desc.data_ptr(), ntensors, max_elems,
+             dtype_code(dst), _stream(dst))

@@ -108,6 +108,73 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
                    float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
                    const void* extra, int ldextra, int dtype, int M, int C, int act, void* stream);
 
+/* ---- ViT encoder (model/transformer.py), dim 256 ------------------------------------------------ */
+
+/* tokens[b][0] = cls_token, tokens[b][1+p] = feat[b*P+p] + pos[p]   (transformer.py:132-139) */
+int mtn_tokens_fwd(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B,
+                   int P, void* stream);
+/* dfeat[b*P+p] = dtok[b][1+p]; dcls[256] = sum_b dtok[b][0] */
+int mtn_tokens_bwd(const void* dtok, void* dfeat, float* dcls, int dtype, int B, int P, void* stream);
+
+/* nn.LayerNorm(256) (transformer.py:33,54): y = (x-mean)*rstd*gamma+beta; mean_rstd f32 [M][2]. */
+int mtn_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                      float* mean_rstd, int dtype, int M, float eps, void* stream);
+/* rows of the f32 partial slab ([rows][512] for LayerNorm, [rows][256] for bias gradients) */
+int mtn_rowslab_rows(int M);
+/* dx = LN'(dy) [+ dres] (dx may alias dres); dgamma_dbeta f32 [2][256] (weight grad, then bias grad) */
+int mtn_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd,
+                      const float* gamma, const void* dres, int lddres, void* dx, int lddx,
+                      float* partial, float* dgamma_dbeta, int dtype, int M, void* stream);
+/* da = dh * gelu'(a), exact erf GELU (transformer.py:35); n elements, contiguous */
+int mtn_gelu_bwd(const void* dh, const void* a, void* da, int dtype, long long n, void* stream);
+/* dbias[256] = column sums of dy[M][256] */
+int mtn_bias_grad(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, void* stream);
+
+/* softmax(q k^T * scale) v per (batch, head), heads merged in the output (transformer.py:62-74).
+ * qkv [B*N][3*H*D]; out [B*N][H*D]; lse f32 [B*H][N]; attn f32 [B][H][N][N] or NULL. D must be 32. */
+int mtn_attention_fwd(const void* qkv, void* out, float* lse, float* attn, int dtype, int B, int N,
+                      int H, int D, float scale, void* stream);
+/* dqkv from dout (flash-style recompute from lse); delta f32 [B*H][N] scratch */
+int mtn_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                      float* delta, void* dqkv, int dtype, int B, int N, int H, int D, float scale,
+                      void* stream);
+
+/* mlp_head = LayerNorm + Linear(256->C) on the cls token (transformer.py:113-116,142-144);
+ * tok_stride = elements between consecutive samples' cls rows; xhat f32 [B][256], mean_rstd [B][2]. */
+int mtn_cls_head_fwd(const void* tok, long long tok_stride, const float* ln_w, const float* ln_b,
+                     const float* W, const float* bias, float* logits, float* xhat, float* mean_rstd,
+                     int dtype, int B, int C, float eps, void* stream);
+/* writes dtok cls rows, dW [C][256], dbias [C], dln_w_b [2][256]; partial f32 [mtn_slab_rows(B)][512] */
+int mtn_cls_head_bwd(const float* dlogits, const float* W, const float* ln_w, const float* ln_b,
+                     const float* xhat, const float* mean_rstd, void* dtok, long long tok_stride,
+                     float* dW, float* dbias, float* dln_w_b, float* partial, int dtype, int B, int C,
+                     void* stream);
+
+/* pose head: bilinear x4 (align_corners) -> ReLU -> 1x1 conv 256->J + bias (transformer.py:146-150);
+ * tok [B][h*w+1][256] (row 0 = cls, skipped); hm f32 NCHW [B][J][4h][4w]. */
+int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B,
+                      int h, int w, int J, void* stream);
+/* writes dtok rows 1.., dW [J][256], dbias [J]; slab f32 [mtn_slab_rows(B)][J*256] */
+int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW,
+                      float* dbias, float* slab, int dtype, int B, int h, int w, int J, void* stream);
+
+/* ---- loss + its gradients (libs/loss.py:4-40, train.py:63-64,75) --------------------------------
+ * losses[3] = (total, ce_weight*CE, JointsMSE); dlogits [B][C], dhm like hm (either may be NULL);
+ * partial f32 [mtn_loss_partial_len(B*J*HW)]. */
+int mtn_loss_partial_len(long long n);
+int mtn_loss_fwd_bwd(const float* logits, const long long* label, const float* hm, const float* target,
+                     const float* target_weight, float* dlogits, float* dhm, float* partial,
+                     float* losses, int B, int C, int J, int HW, float ce_weight, void* stream);
+
+/* ---- optimizer (train.py:50-51: AdamW defaults) --------------------------------------------------
+ * state f32[16]: lr, beta1, beta2, eps, weight_decay, step, bias_corr1, bias_corr2, grad_scale.
+ * One call = step += 1, bias corrections, decoupled decay and the Adam update over n elements. */
+int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, float* state, void* stream);
+/* repack fp32 master weights (OIHW) into kernel operand layouts; desc int32 [ntensors][6] =
+ * {src_off, dst_off, O, I, taps, mode}; mode 0: [O][tap][I] (forward), 1: [I][tap][O] (dgrad). */
+int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors, int max_elems,
+                     int dtype, void* stream);
+
 /* test hook: key 1 = use ds_read_b64_tr_b16 operand reads in wgrad (default 1) */
 int mtn_debug_set(int key, int value);
 
