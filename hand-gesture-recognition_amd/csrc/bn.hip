@@ -80,6 +80,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
 }
 
+// eval mode (model.eval()): normalise with the running statistics
+__global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                      float eps, float* __restrict__ scale_shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] * rsqrtf(rvar[c] + eps);
+        scale_shift[c] = sc;
+        scale_shift[C + c] = beta[c] - rmean[c] * sc;
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ ss,
                                                          const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
@@ -243,6 +255,13 @@ int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float*
     MTN_LAUNCH(bn_finalize_kernel, dim3(mtn_cdiv(C, 64)), dim3(256), 0, stream, part, rows, C, (float)count, gamma, beta,
                rmean, rvar, nbt, momentum, eps, scale_shift, mean_rstd);
     return mtn_check_launch("bn_finalize");
+}
+
+int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                    float* scale_shift, int C, hipStream_t stream) {
+    MTN_REQUIRE(C > 0, "bn_eval: C=%d", C);
+    MTN_LAUNCH(bn_eval_kernel, dim3(mtn_cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, rmean, rvar, eps, scale_shift, C);
+    return mtn_check_launch("bn_eval");
 }
 
 int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res, int ldr, void* out, int ldo, int dtype,

@@ -143,6 +143,11 @@ int mtn_bn_finalize(float* stats, int tiles, int C, long long count, const float
                                num_batches_tracked, momentum, eps, scale_shift, mean_rstd, (hipStream_t)stream);
 }
 
+int mtn_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* scale_shift, int C, void* stream) {
+    return mtn_bn_eval_run(gamma, beta, running_mean, running_var, eps, scale_shift, C, (hipStream_t)stream);
+}
+
 int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void* res, int ldres, void* out,
                    int ldo, int dtype, int M, int C, int act, void* stream) {
     return mtn_bn_act_fwd_run(y, ldy, scale_shift, res, ldres, out, ldo, dtype, M, C, act, (hipStream_t)stream);

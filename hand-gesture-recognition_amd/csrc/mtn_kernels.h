@@ -109,3 +109,5 @@ int mtn_loss_run(const float* logits, const long long* label, const float* hm, c
                  float* dhm, float* partial, float* losses, int B, int C, int J, int HW, float ce_weight, hipStream_t stream);
 int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* state, hipStream_t stream);
 int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream);
+int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                    float* scale_shift, int C, hipStream_t stream);

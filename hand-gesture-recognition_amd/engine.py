@@ -1,0 +1,371 @@
+"""Static execution plan of the MultiTaskNet hot path: explicit forward and backward over
+preallocated HBM buffers, every arithmetic step a HIP kernel reached through ``ops`` (C ABI).
+
+Data layout in HBM
+  * activations: NHWC, storage dtype T (bf16 throughput mode / fp32 validation mode);
+  * the GELAN concat (model/gelan.py:138,142) is ONE [B,H,W,2C] buffer per stage: cv1 writes
+    channels [0,C), the two residual branches write [C,3C/2) and [3C/2,2C), cv4 reads it whole --
+    ``chunk`` and ``cat`` cost nothing; gradients use a mirror buffer and accumulate in place;
+  * every Conv keeps its raw (pre-BatchNorm) output: it is what BN/SiLU backward needs;
+  * tokens [B, N, 256]; qkv [B*N, 768]; attention reads/writes those layouts directly;
+  * parameters / gradients: flat fp32 buffers owned by the module (nn.Parameters are views);
+    kernels read a repacked copy in T ([O][kh][kw][I] forward, [I][kh][kw][O] data-gradient).
+  * all parameter gradients are WRITTEN (not accumulated) once per backward.
+
+Reference op order: model/multitasknet.py:24-29 -> model/gelan.py:165-176 ->
+model/transformer.py:129-152; loss libs/loss.py + train.py:63-64,75.
+"""
+import torch
+
+from . import ops
+
+_ACT = {True: ops.ACT_SILU, False: ops.ACT_NONE}
+
+
+class _Unit:
+    """One Conv2d(+BatchNorm) site and its per-layer buffers."""
+
+    def __init__(self, mod, cin, cout, k, s, hin, win, act=True, bn=True):
+        self.mod, self.cin, self.cout, self.k, self.s, self.act, self.bn = mod, cin, cout, k, s, act, bn
+        self.hin, self.win = hin, win
+        self.hout, self.wout = (hin + 2 * (k // 2) - k) // s + 1, (win + 2 * (k // 2) - k) // s + 1
+
+
+class Engine:
+    def __init__(self, model, batch, dtype):
+        self.model, self.B, self.dt = model, int(batch), dtype
+        self.dev = model.flat_params.device
+        H, W = model.image_size
+        if H % 16 or W % 16:
+            raise ValueError("image_size must be a multiple of 16 (total stride of GELANNet)")
+        self.H, self.W = H, W
+        self.fh, self.fw = H // 16, W // 16
+        self.P = self.fh * self.fw
+        self.N = self.P + 1
+        self.J, self.C = model.num_joints, model.num_classes
+        self.heads, self.hd, self.dim = 8, 32, 256
+        self._bufs = {}
+        self._build()
+
+    # ---------------------------------------------------------------- buffers
+    def _new(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dt, device=self.dev)
+
+    def _f32(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def _build(self):
+        B, enc = self.B, self.model.encoder
+        H2, W2 = self.H // 2, self.W // 2
+        units = []
+
+        def unit(mod, hin, win, bn=True):
+            if isinstance(mod, torch.nn.Conv2d):
+                u = _Unit(mod, mod.in_channels, mod.out_channels, mod.kernel_size[0], mod.stride[0], hin, win,
+                          act=False, bn=False)
+            else:
+                u = _Unit(mod, mod.c1, mod.c2, mod.k, mod.s, hin, win, act=mod.has_act, bn=bn)
+            units.append(u)
+            return u
+
+        self.u_conv1 = unit(enc.conv1, self.H, self.W)
+        self.u_conv2 = unit(enc.conv2, H2, W2)
+        self.stages = []
+        h, w = self.H // 4, self.W // 4
+        for blk, down in ((enc.cspelan1, enc.down1), (enc.cspelan2, enc.down2), (enc.cspelan3, None)):
+            st = {"C": blk.c_out, "h": h, "w": w}
+            st["cv1"] = unit(blk.cv1, h, w)
+            st["b2c1"] = unit(blk.cv2[0].cv1, h, w)
+            st["b2c2"] = unit(blk.cv2[0].cv2, h, w)
+            st["b3c1"] = unit(blk.cv3[0].cv1, h, w)
+            st["b3c2"] = unit(blk.cv3[0].cv2, h, w)
+            st["cv4"] = unit(blk.cv4, h, w)
+            st["down"] = unit(down, h, w) if down is not None else None
+            self.stages.append(st)
+            h, w = h // 2, w // 2
+        self.u_proj = unit(self.model.proj, self.fh, self.fw)
+        self.units = units
+
+        # ---- packed weights: descriptor table for mtn_pack_weights ---------------------------------
+        flat = self.model.flat_params
+        desc, off = [], 0
+
+        def add_pack(p, O, I, taps, mode):
+            nonlocal off
+            src = (p.data_ptr() - flat.data_ptr()) // 4
+            desc.append([src, off, O, I, taps, mode])
+            o = off
+            off += O * I * taps
+            off = (off + 7) & ~7           # keep every packed tensor 16-byte aligned
+            return o, O * I * taps
+
+        packs = []
+        for u in units:
+            wgt = u.mod.weight if isinstance(u.mod, torch.nn.Conv2d) else u.mod.conv.weight
+            u.weight = wgt
+            u.pk_f = add_pack(wgt, u.cout, u.cin, u.k * u.k, 0)
+            u.pk_d = add_pack(wgt, u.cout, u.cin, u.k * u.k, 1) if u is not self.u_conv1 else None
+            packs.append(u)
+        self.layers = []
+        for attn, ff in self.model.decoder.transformer.layers:
+            L = {"attn": attn, "ff": ff}
+            for key, lin in (("qkv", attn.to_qkv), ("out", attn.to_out), ("fc1", ff.net[1]), ("fc2", ff.net[4])):
+                L[key] = lin
+                L[key + "_f"] = add_pack(lin.weight, lin.out_features, lin.in_features, 1, 0)
+                L[key + "_d"] = add_pack(lin.weight, lin.out_features, lin.in_features, 1, 1)
+            self.layers.append(L)
+        self.wpack = self._new((off,))
+        self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=self.dev)
+        self.pack_n, self.pack_max = len(desc), max(d[2] * d[3] * d[4] for d in desc)
+
+        def pview(t):
+            o, n = t
+            return self.wpack[o:o + n]
+
+        for u in units:
+            u.wf = pview(u.pk_f)
+            u.wd = pview(u.pk_d) if u.pk_d is not None else None
+        for L in self.layers:
+            for key in ("qkv", "out", "fc1", "fc2"):
+                L[key + "_wf"] = pview(L[key + "_f"])
+                L[key + "_wd"] = pview(L[key + "_d"])
+
+        # ---- per-unit buffers -------------------------------------------------------------------------
+        max_dy = max_part = max_ws = 0
+        for u in units:
+            M = B * u.hout * u.wout
+            u.M = M
+            u.raw = self._new((B, u.hout, u.wout, u.cout))
+            if u.bn:
+                tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_stats_tiles(M, u.cout)
+                u.tiles = tiles
+                u.stats = self._f32(ops.slab_rows(tiles), 2, u.cout)
+                u.ss, u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout), self._f32(2, u.cout)
+                max_part = max(max_part, ops.bn_bwd_partial_rows(M) * 2 * u.cout)
+            max_dy = max(max_dy, M * u.cout)
+            if u is self.u_conv1:
+                self.conv1_part = self._f32(ops.conv1_wgrad_partial_rows(B, self.H, self.W), 64 * 27)
+            else:
+                max_ws = max(max_ws, ops.conv_wgrad_workspace_bytes(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s))
+        Mt = B * self.N
+        for n_out, k_in in ((768, 256), (256, 256)):
+            max_ws = max(max_ws, ops.linear_wgrad_workspace_bytes(self.dt, Mt, n_out, k_in))
+        self.dyraw = self._new((max_dy,))
+        self.bn_part = self._f32(max_part)
+        self.wgrad_ws = self._f32(max_ws // 4 + 4)
+
+        # ---- activations and their gradients ----------------------------------------------------------
+        u1, u2 = self.u_conv1, self.u_conv2
+        self.a1 = self._new((B, u1.hout, u1.wout, 64))
+        self.a2 = self._new((B, u2.hout, u2.wout, 128))
+        self.g_a1, self.g_a2 = torch.empty_like(self.a1), torch.empty_like(self.a2)
+        for st in self.stages:
+            C, h, w = st["C"], st["h"], st["w"]
+            st["cat"], st["g_cat"] = self._new((B, h, w, 2 * C)), self._new((B, h, w, 2 * C))
+            st["t2"], st["t3"] = self._new((B, h, w, C // 2)), self._new((B, h, w, C // 2))
+            st["g_t"] = self._new((B, h, w, C // 2))
+            st["out"], st["g_out"] = self._new((B, h, w, C)), self._new((B, h, w, C))
+            if st["down"] is not None:
+                d = st["down"]
+                st["dn"], st["g_dn"] = self._new((B, d.hout, d.wout, d.cout)), self._new((B, d.hout, d.wout, d.cout))
+        # ViT
+        D = self.dim
+        self.pos = self.model.decoder.pos_embedding.to(self.dev, torch.float32).contiguous()
+        self.feat = self.u_proj.raw.view(B * self.P, D)           # proj output == token features
+        self.g_feat = self._new((B * self.P, D))
+        self.x = [self._new((B, self.N, D)) for _ in range(2 * len(self.layers) + 1)]   # residual stream states
+        self.G = self._new((B, self.N, D))                        # gradient of the residual stream
+        for L in self.layers:
+            L["xn"], L["mr1"] = self._new((Mt, D)), self._f32(Mt, 2)
+            L["qkvb"], L["lse"] = self._new((Mt, 3 * D)), self._f32(B * self.heads, self.N)
+            L["ao"] = self._new((Mt, D))
+            L["xn2"], L["mr2"] = self._new((Mt, D)), self._f32(Mt, 2)
+            L["a"], L["hg"] = self._new((Mt, D)), self._new((Mt, D))
+        self.t_a, self.t_b = self._new((Mt, D)), self._new((Mt, D))     # backward temporaries
+        self.t_qkv = self._new((Mt, 3 * D))
+        self.delta = self._f32(B * self.heads, self.N)
+        self.row_part = self._f32(ops.rowslab_rows(Mt), 2 * D)
+        self.attn = self._f32(B, self.heads, self.N, self.N)
+        self.logits = self._f32(B, self.C)
+        self.hm = self._f32(B, self.J, 4 * self.fh, 4 * self.fw)
+        self.cls_xhat, self.cls_mr = self._f32(B, D), self._f32(B, 2)
+        self.cls_part = self._f32(ops.slab_rows(B), 2 * D)
+        self.pose_slab = self._f32(ops.slab_rows(B), self.J * D)
+        self.dlogits, self.dhm = self._f32(B, self.C), torch.empty_like(self.hm)
+        self.loss_part = self._f32(ops.loss_partial_len(self.hm.numel()))
+        self.losses = self._f32(3)
+
+    # ---------------------------------------------------------------- helpers
+    @staticmethod
+    def _g(p):
+        return p._mtn_grad
+
+    def pack_weights(self):
+        ops.pack_weights(self.model.flat_params, self.wpack, self.pack_desc, self.pack_n, self.pack_max)
+
+    def _dy(self, u):
+        return self.dyraw[:u.M * u.cout].view(self.B, u.hout, u.wout, u.cout)
+
+    def _bn_fwd(self, u, out, training, res=None):
+        bn = u.mod.bn
+        if training:
+            ops.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
+        else:
+            ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, u.ss, bn.eps)
+        ops.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
+
+    def _conv(self, u, x, out, training, res=None):
+        """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87)"""
+        ops.conv_fwd(x, u.wf, u.raw, u.stats if training else None, u.k, u.s)
+        self._bn_fwd(u, out, training, res)
+
+    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None):
+        """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res])."""
+        bn, dy = u.mod.bn, self._dy(u)
+        ops.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
+                       dy, _ACT[u.act or res is not None], dres=dres, extra=dres)
+        ops.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
+        if g_in is not None:
+            ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s)
+
+    # ---------------------------------------------------------------- forward
+    def backbone_forward(self, x, training=True):
+        """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512]."""
+        u1 = self.u_conv1
+        self.x_in = x
+        ops.conv1_fwd(x, u1.wf, u1.raw, u1.stats if training else None)
+        self._bn_fwd(u1, self.a1, training)
+        self._conv(self.u_conv2, self.a1, self.a2, training)
+        cur = self.a2
+        for st in self.stages:
+            C, cat = st["C"], st["cat"]
+            h2 = C // 2
+            st["in"] = cur
+            self._conv(st["cv1"], cur, cat[..., :C], training)                           # y0 | y1
+            self._conv(st["b2c1"], cat[..., h2:C], st["t2"], training)
+            self._conv(st["b2c2"], st["t2"], cat[..., C:C + h2], training, res=cat[..., h2:C])      # y2
+            self._conv(st["b3c1"], cat[..., C:C + h2], st["t3"], training)
+            self._conv(st["b3c2"], st["t3"], cat[..., C + h2:], training, res=cat[..., C:C + h2])   # y3
+            self._conv(st["cv4"], cat, st["out"], training)
+            cur = st["out"]
+            if st["down"] is not None:
+                self._conv(st["down"], cur, st["dn"], training)
+                cur = st["dn"]
+        return cur
+
+    def forward(self, x, training=True, want_attn=True):
+        """MultiTaskNet.forward (model/multitasknet.py:24-29) -> (logits, heatmaps, attnmap)."""
+        assert tuple(x.shape) == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
+        self.pack_weights()
+        feats = self.backbone_forward(x, training)
+        up = self.u_proj
+        ops.conv_fwd(feats, up.wf, up.raw, None, 1, 1)                                   # multitasknet.py:26
+        dec = self.model.decoder
+        ops.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                    # transformer.py:132-139
+        B, N, D, Hh = self.B, self.N, self.dim, self.heads
+        Mt = B * N
+        for i, L in enumerate(self.layers):
+            x0, x1, x2 = self.x[2 * i].view(Mt, D), self.x[2 * i + 1].view(Mt, D), self.x[2 * i + 2].view(Mt, D)
+            at, ff = L["attn"], L["ff"]
+            ops.layernorm_fwd(x0, at.norm.weight, at.norm.bias, L["xn"], L["mr1"], at.norm.eps)
+            ops.linear_fwd(L["xn"], L["qkv_wf"], L["qkvb"])
+            last = i == len(self.layers) - 1
+            ops.attention_fwd(L["qkvb"], L["ao"], L["lse"], self.attn if (last and want_attn) else None,
+                              B, N, Hh, self.hd, at.scale)
+            ops.linear_fwd(L["ao"], L["out_wf"], x1, res=x0)                             # x = attn(x) + x
+            ln = ff.net[0]
+            ops.layernorm_fwd(x1, ln.weight, ln.bias, L["xn2"], L["mr2"], ln.eps)
+            ops.linear_fwd(L["xn2"], L["fc1_wf"], L["hg"], bias=ff.net[1].bias, act=ops.ACT_GELU, aux_out=L["a"])
+            ops.linear_fwd(L["hg"], L["fc2_wf"], x2, bias=ff.net[4].bias, res=x1)       # x = ff(x) + x
+        xl = self.x[-1]
+        head = dec.mlp_head
+        ops.cls_head_fwd(xl, head[0].weight, head[0].bias, head[1].weight, head[1].bias, self.logits,
+                         self.cls_xhat, self.cls_mr, head[0].eps)
+        pw = dec.simple_decoder[1]
+        ops.pose_head_fwd(xl, pw.weight, pw.bias, self.hm, self.fh, self.fw)
+        return self.logits, self.hm, (self.attn if want_attn else None)
+
+    # ---------------------------------------------------------------- loss
+    def loss(self, label, target, target_weight, with_grads=True):
+        """total = 0.001*CE + JointsMSE (train.py:63-64,75); fills dlogits/dhm when with_grads."""
+        ops.loss_fwd_bwd(self.logits, label, self.hm, target, target_weight,
+                         self.dlogits if with_grads else None, self.dhm if with_grads else None,
+                         self.loss_part, self.losses)
+        return self.losses
+
+    # ---------------------------------------------------------------- backward
+    def backbone_backward(self, g_feats):
+        """Backward of backbone_forward given the gradient of its NHWC output (written into g buffers)."""
+        g_cur = g_feats
+        for st in reversed(self.stages):
+            C, cat, gc = st["C"], st["cat"], st["g_cat"]
+            h2 = C // 2
+            if st["down"] is not None:
+                self._conv_bwd(st["down"], g_cur, st["out"], st["g_out"])
+                g_cur = st["g_out"]
+            self._conv_bwd(st["cv4"], g_cur, cat, gc)
+            # branch cv3 (y3 = block(y2)): residual gradient accumulates into g_cat[y2]
+            self._conv_bwd(st["b3c2"], gc[..., C + h2:], st["t3"], st["g_t"], res=cat[..., C:C + h2], dres=gc[..., C:C + h2])
+            self._conv_bwd(st["b3c1"], st["g_t"], cat[..., C:C + h2], gc[..., C:C + h2], g_in_res=gc[..., C:C + h2])
+            # branch cv2 (y2 = block(y1))
+            self._conv_bwd(st["b2c2"], gc[..., C:C + h2], st["t2"], st["g_t"], res=cat[..., h2:C], dres=gc[..., h2:C])
+            self._conv_bwd(st["b2c1"], st["g_t"], cat[..., h2:C], gc[..., h2:C], g_in_res=gc[..., h2:C])
+            g_in = self.g_a2 if st is self.stages[0] else self.stages[self.stages.index(st) - 1]["g_dn"]
+            self._conv_bwd(st["cv1"], gc[..., :C], st["in"], g_in)
+            g_cur = g_in
+        self._conv_bwd(self.u_conv2, self.g_a2, self.a1, self.g_a1)
+        u1, bn = self.u_conv1, self.u_conv1.mod.bn
+        dy = self._dy(u1)
+        ops.bn_act_bwd(self.g_a1, u1.raw, None, u1.ss, u1.mr, self.bn_part, u1.coef, self._g(bn.weight),
+                       self._g(bn.bias), dy, ops.ACT_SILU)
+        ops.conv1_wgrad(self.x_in, dy, self._g(u1.weight), self.conv1_part)
+
+    def backward(self, dlogits=None, dhm=None):
+        """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
+        dlogits = self.dlogits if dlogits is None else dlogits
+        dhm = self.dhm if dhm is None else dhm
+        dec, g = self.model.decoder, self._g
+        B, N, D, Hh = self.B, self.N, self.dim, self.heads
+        Mt = B * N
+        G, Gm = self.G, self.G.view(Mt, D)
+        head, pw = dec.mlp_head, dec.simple_decoder[1]
+        xl = self.x[-1]
+        ops.cls_head_bwd(dlogits, head[1].weight, head[0].weight, head[0].bias, self.cls_xhat, self.cls_mr, G,
+                         g(head[1].weight), g(head[1].bias), self._pair(head[0].weight, head[0].bias), self.cls_part)
+        ops.pose_head_bwd(xl, pw.weight, dhm, G, g(pw.weight), g(pw.bias), self.pose_slab, self.fh, self.fw)
+        for i in reversed(range(len(self.layers))):
+            L = self.layers[i]
+            x0, x1 = self.x[2 * i].view(Mt, D), self.x[2 * i + 1].view(Mt, D)
+            at, ff = L["attn"], L["ff"]
+            fc1, fc2, ln2 = ff.net[1], ff.net[4], ff.net[0]
+            # x2 = fc2(gelu(fc1(LN(x1)))) + x1
+            ops.bias_grad(Gm, self.row_part, g(fc2.bias))
+            ops.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
+            ops.linear_fwd(Gm, L["fc2_wd"], self.t_a)                       # d hgelu
+            ops.gelu_bwd(self.t_a, L["a"], self.t_b)                        # d a
+            ops.bias_grad(self.t_b, self.row_part, g(fc1.bias))
+            ops.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
+            ops.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
+            ops.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, self.row_part,
+                              self._pair(ln2.weight, ln2.bias), dres=Gm)
+            # x1 = to_out(attention(LN(x0))) + x0
+            ops.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
+            ops.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
+            ops.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
+            ops.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
+            ops.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
+            ops.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, self.row_part,
+                              self._pair(at.norm.weight, at.norm.bias), dres=Gm)
+        ops.tokens_bwd(G, self.g_feat, g(dec.cls_token))
+        up, last = self.u_proj, self.stages[-1]
+        gf = self.g_feat.view(self.B, self.fh, self.fw, D)
+        ops.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
+        ops.conv_dgrad(gf, up.wd, last["g_out"], None, 1, 1)
+        self.backbone_backward(last["g_out"])
+
+    def _pair(self, w, b):
+        """[2][256] gradient slot of a LayerNorm (weight grad then bias grad, adjacent in the flat buffer)."""
+        gw, gb = self._g(w), self._g(b)
+        assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4, "LayerNorm weight/bias grads must be adjacent"
+        return gw

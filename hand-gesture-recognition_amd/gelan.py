@@ -1,0 +1,85 @@
+"""GELAN backbone -- host-side mirror of the reference's ``model/gelan.py`` interface.
+
+These modules own the parameters (same names, shapes, construction order and default
+initialisation as the reference, so ``state_dict`` keys and seeded init match) and describe the
+layer graph; the arithmetic runs in HIP kernels scheduled by ``engine.Engine``.  None of the
+torch modules held here is ever *called*.
+
+Reference: ``autopad`` gelan.py:5-15, ``Conv`` :18-56, ``ResBasicBlock`` :59-87,
+``GELANBlock`` :124-142, ``GELANNet`` :145-176.  ``ResBottleneck`` (:90-121) is never
+instantiated by the reference's spec table (:148-151) and is not provided.
+"""
+import torch
+from torch import nn
+
+
+def autopad(k, p=None, d=1):
+    """'same' padding for kernel ``k`` (gelan.py:5-15): k//2 at dilation 1."""
+    if d > 1:
+        k = d * (k - 1) + 1
+    return k // 2 if p is None else p
+
+
+class Conv(nn.Module):
+    """Conv2d(bias=False) + BatchNorm2d + SiLU (``act=True``) or identity (gelan.py:18-56)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        if g != 1 or d != 1:
+            raise NotImplementedError("the MultiTaskNet hot path only uses groups=1, dilation=1")
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.c1, self.c2, self.k, self.s, self.has_act = c1, c2, k, s, act is True
+
+    def forward(self, x):
+        raise RuntimeError("Conv runs inside the fused plan of GELANNet / MultiTaskNet (engine.py)")
+
+
+class ResBasicBlock(nn.Module):
+    """SiLU(x + bn(conv3x3(SiLU(bn(conv3x3(x)))))) with c1 == c2 (gelan.py:59-87)."""
+
+    def __init__(self, c1, c2, shortcut=True):
+        super().__init__()
+        if c1 != c2 or not shortcut:
+            raise NotImplementedError("GELANNet only builds ResBasicBlock(c, c, shortcut=True)")
+        self.cv1 = Conv(c1, c2, 3, 1)
+        self.cv2 = Conv(c2, c2, 3, 1, act=False)
+
+    def forward(self, x):
+        raise RuntimeError("ResBasicBlock runs inside the fused plan (engine.py)")
+
+
+class GELANBlock(nn.Module):
+    """cv1 -> chunk(2) -> cv2 -> cv3 -> cat -> cv4 (gelan.py:124-142), one block per branch."""
+
+    def __init__(self, c_in, c_out, c_hid1, c_hid2, block=ResBasicBlock, nblocks=1):
+        super().__init__()
+        if nblocks != 1 or c_hid1 // 2 != c_hid2:
+            raise NotImplementedError("only the 'small' GELAN spec (1 block per branch) is built")
+        self.cv1 = Conv(c_in, c_hid1, 1, 1)
+        self.cv2 = nn.Sequential(block(c_hid1 // 2, c_hid2))
+        self.cv3 = nn.Sequential(block(c_hid2, c_hid2))
+        self.cv4 = Conv(c_hid1 + 2 * c_hid2, c_out, 1, 1)
+        self.c_in, self.c_out, self.c_hid1, self.c_hid2 = c_in, c_out, c_hid1, c_hid2
+
+    def forward(self, x):
+        raise RuntimeError("GELANBlock runs inside the fused plan (engine.py)")
+
+
+class GELANNet(nn.Module):
+    """GELANNet('small') (gelan.py:145-176): total stride 16, 3 -> 512 channels."""
+
+    def __init__(self, gelan_type="small"):
+        super().__init__()
+        if gelan_type != "small":
+            raise NotImplementedError("MultiTaskNet hard-codes GELANNet('small') (multitasknet.py:12)")
+        self.conv1 = Conv(3, 64, 3, 2)
+        self.conv2 = Conv(64, 128, 3, 2)
+        self.cspelan1 = GELANBlock(128, 128, 128, 64)
+        self.down1 = Conv(128, 256, 3, 2)
+        self.cspelan2 = GELANBlock(256, 256, 256, 128)
+        self.down2 = Conv(256, 512, 3, 2)
+        self.cspelan3 = GELANBlock(512, 512, 512, 256)
+
+    def forward(self, x):
+        raise RuntimeError("use MultiTaskNet (or engine.Engine.backbone_*) to run the backbone")

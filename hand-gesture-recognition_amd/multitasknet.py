@@ -1,0 +1,128 @@
+"""MultiTaskNet -- drop-in for the reference's ``model/multitasknet.py`` on MI355X.
+
+Same constructor, same ``forward(x) -> (cls_out, hmap_out, attnmap)``, same 180-key
+``state_dict`` (reference: model/multitasknet.py:8-29; callers train.py:33,61, export.py:27,44).
+The forward/backward arithmetic is the HIP plan in ``engine.py``; this class owns parameters,
+keeps them in one flat fp32 buffer (so AdamW and the RCCL gradient all-reduce are one launch /
+one bucket each) and connects the plan to autograd.
+
+Deviations from the reference module, all deliberate:
+  * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174)
+    and, like the other outputs' backing storage, is overwritten by the next forward;
+  * parameter gradients are written (not accumulated) into ``p.grad`` by each backward -- the
+    reference's loop zeroes them every step (Lightning), so training is unaffected;
+  * the input needs no gradient (none is produced);
+  * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode)
+    or fp32 storage / exact-f32 MFMA (validation mode, the one held to 1e-3 of the reference).
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import lib
+from .engine import Engine
+from .gelan import GELANNet
+from .transformer import ViT
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+
+
+class _PlanFunction(torch.autograd.Function):
+    """Connects Engine.forward/backward to autograd (one node for the whole network)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, model, engine):
+        logits, hm, attn = engine.forward(x, training=model.training)
+        ctx.model, ctx.engine = model, engine
+        ctx.mark_non_differentiable(attn)
+        return logits.clone(), hm.clone(), attn
+
+    @staticmethod
+    def backward(ctx, dlogits, dhm, _dattn):
+        eng = ctx.engine
+        dlogits = torch.zeros_like(eng.logits) if dlogits is None else dlogits.contiguous()
+        dhm = torch.zeros_like(eng.hm) if dhm is None else dhm.contiguous()
+        eng.backward(dlogits, dhm)
+        ctx.model.publish_grads()
+        return torch.zeros(1, device=dlogits.device), None, None, None
+
+
+class MultiTaskNet(nn.Module):
+    def __init__(self, num_joints, num_classes, image_size, compute_dtype=None):
+        super().__init__()
+        # identical construction order to the reference -> identical seeded default init
+        self.encoder = GELANNet("small")                                   # multitasknet.py:12
+        self.proj = nn.Conv2d(512, 256, 1, bias=False)                     # multitasknet.py:13
+        self.decoder = ViT(num_classes=num_classes, num_joints=num_joints,
+                           feature_size=[image_size[0] // 16, image_size[1] // 16],
+                           dim=256, depth=4, heads=8, head_dim=32, mlp_dim=256)   # multitasknet.py:14-22
+        self.num_joints, self.num_classes = int(num_joints), int(num_classes)
+        self.image_size = (int(image_size[0]), int(image_size[1]))
+        if compute_dtype is None:
+            compute_dtype = _DTYPES[os.environ.get("MTN_COMPUTE_DTYPE", "bf16").lower()]
+        self.compute_dtype = compute_dtype
+        self._engines = {}
+        self._anchor = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _flatten(self):
+        params = list(self.parameters())
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        n_pad = (n + 3) & ~3
+        flat = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        grads = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                flat[off:off + k].copy_(p.data.reshape(-1).to(torch.float32))
+                p.data = flat[off:off + k].view(p.shape)
+                p._mtn_grad = grads[off:off + k].view(p.shape)
+                p.grad = None
+                off += k
+        self.flat_params, self.flat_grads, self.n_params = flat, grads, n
+        self._engines = {}
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)       # .to() / .cuda() / .float(): params get new storage
+        self._flatten()
+        return self
+
+    def publish_grads(self):
+        """Expose the flat gradient buffer through ``p.grad`` (views, no copies)."""
+        for p in self.parameters():
+            if p.grad is not p._mtn_grad:
+                p.grad = p._mtn_grad
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+        self._engines = {}
+        return self
+
+    # ------------------------------------------------------------------ execution
+    def engine(self, batch):
+        """The execution plan (buffers + kernel schedule) for one batch size."""
+        if self.flat_params.device.type != "cuda" and lib.loaded_path() in (None, lib.HIP_LIB):
+            raise RuntimeError("MultiTaskNet runs on an MI355X only: move the module to 'cuda' "
+                               "(there is no CPU path; libmtn_hip.so is required)")
+        key = (int(batch), self.compute_dtype)
+        eng = self._engines.get(key)
+        if eng is None:
+            self._engines = {key: Engine(self, batch, self.compute_dtype)}    # one live plan at a time
+            eng = self._engines[key]
+        return eng
+
+    def forward(self, x):
+        """x float32 [B,3,H,W] -> (cls_out [B,classes], hmap_out [B,joints,H/4,W/4], attnmap [B,8,N,N])."""
+        if x.dim() != 4 or x.shape[1] != 3 or tuple(x.shape[2:]) != self.image_size:
+            raise ValueError(f"expected [B,3,{self.image_size[0]},{self.image_size[1]}], got {tuple(x.shape)}")
+        x = x.to(torch.float32).contiguous()
+        eng = self.engine(x.shape[0])
+        if torch.is_grad_enabled() and self.training:
+            return _PlanFunction.apply(self._anchor, x, self, eng)
+        logits, hm, attn = eng.forward(x, training=self.training)
+        return logits.clone(), hm.clone(), attn

@@ -116,6 +116,11 @@ def bn_finalize(stats, tiles, count, gamma, beta, running_mean, running_var, nbt
              mean_rstd.data_ptr(), _stream(stats))
 
 
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, scale_shift, eps=1e-5):
+    lib.call("mtn_bn_eval_scale_shift", gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+             running_var.data_ptr(), eps, scale_shift.data_ptr(), gamma.numel(), _stream(gamma))
+
+
 def bn_act_fwd(y, scale_shift, out, act, res=None):
     C = y.shape[-1]
     M = y.numel() // C

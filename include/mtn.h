@@ -95,6 +95,11 @@ int mtn_bn_finalize(float* stats, int tiles, int C, long long count, const float
                     long long* num_batches_tracked, float momentum, float eps, float* scale_shift,
                     float* mean_rstd, void* stream);
 
+/* eval mode (module.eval()): scale_shift from the running statistics instead of batch statistics. */
+int mtn_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* scale_shift, int C,
+                            void* stream);
+
 /* out = act(y*scale + shift [+ res]), act in {NONE, SILU}. */
 int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void* res, int ldres,
                    void* out, int ldo, int dtype, int M, int C, int act, void* stream);

@@ -1,0 +1,123 @@
+"""End-to-end parity of the HIP MultiTaskNet against the oracle / the reference's golden vectors.
+
+fp32 validation mode is held to 1e-3 (max-norm relative) as BASELINE.json's north_star states;
+bf16 throughput mode to the separately stated 5e-2 (the reference itself
+drifts 0.4-2.5e-2 when run in bf16).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mtn_oracle as O
+from backend import Backend, rel_err
+from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+
+
+def _setup(be, name, golden_dir, dtype):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, S, seed = (int(v) for v in g["meta"])
+    sd = O.synthetic_state_dict(21, 19, seed=seed)
+    batch = O.synthetic_batch(B, S, seed=42 + seed)
+    model = MultiTaskNet(21, 19, [S, S], compute_dtype=dtype)
+    model.load_state_dict(sd, strict=True)
+    model.to(be.device)
+    model.train()
+    return g, sd, batch, model
+
+
+def _run(be, name, golden_dir, dtype, tol_out, tol_grad):
+    g, sd, batch, model = _setup(be, name, golden_dir, dtype)
+    img, label, target, tw = (t.to(be.device) for t in batch)
+    cls_out, hmap, attn = model(img)
+    # the reference's loss recipe (train.py:63-64,75) in torch ops on our outputs -> our backward
+    total, cl, jl = O.total_loss(cls_out, hmap, label, target, tw)
+    total.backward()
+    be.sync()
+    assert rel_err(cls_out, torch.from_numpy(g["cls_out"])) < tol_out
+    assert rel_err(hmap, torch.from_numpy(g["hmap_out"])) < tol_out
+    assert rel_err(attn[:, :, 0, :], torch.from_numpy(g["attn_row0"])) < tol_out
+    assert rel_err(attn[0, 0], torch.from_numpy(g["attn_b0h0"])) < tol_out
+    assert float((attn.sum(-1) - 1).abs().max()) < 1e-3
+    assert abs(float(total) - g["losses"][0]) / abs(g["losses"][0]) < tol_out
+    # BatchNorm running statistics after one train-mode forward
+    msd = model.state_dict()
+    bn = torch.cat([msd[str(k)].flatten().cpu() for k in g["bn_keys"]])
+    assert rel_err(bn, torch.from_numpy(g["bn_running"])) < tol_out
+    assert all(int(msd[k]) == 1 for k in msd if k.endswith("num_batches_tracked"))
+    # gradients: every parameter against the oracle (which is pinned to the reference)
+    (_, _, _), _, grads = O.forward_backward({k: v.clone() for k, v in sd.items()}, batch)
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        e = rel_err(p.grad, grads[k])
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < tol_grad, worst
+    for k in g.files:
+        if k.startswith("grad."):
+            assert rel_err(dict(model.named_parameters())[k[5:]].grad, torch.from_numpy(g[k])) < tol_grad, k
+    return model
+
+
+def test_tiny_fp32_emu(golden_dir):
+    """Kernel logic end to end on the CPU fiber executor (32x32 images, fp32 validation mode)."""
+    _run(Backend("emu"), "tiny_b3_s32", golden_dir, torch.float32, 1e-3, 1e-3)
+
+
+def test_tiny_bf16_emu(golden_dir):
+    _run(Backend("emu"), "tiny_b3_s32", golden_dir, torch.bfloat16, 5e-2, 0.25)
+
+
+def test_state_dict_contract():
+    """180 keys, strict load both ways, Lightning-style 'model.' prefix stripped (export.py:34-40)."""
+    model = MultiTaskNet(21, 19, [64, 64])
+    sd = O.synthetic_state_dict(21, 19, seed=3)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    assert [tuple(v.shape) for v in model.state_dict().values()] == [tuple(v.shape) for v in sd.values()]
+    ckpt = {"model." + k: v for k, v in sd.items()}
+    model.load_state_dict({k[len("model."):]: v for k, v in ckpt.items()}, strict=True)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert sum(p.numel() for p in model.parameters()) == 7_409_000
+    assert len(list(model.parameters())) == 114
+    assert "pos_embedding" not in "".join(model.state_dict().keys())
+    assert torch.equal(model.decoder.pos_embedding, O.pos_emb_sincos_2d(4, 4, 256))
+
+
+def test_default_init_matches_reference_order():
+    """Same module construction order => same seeded default init as the reference (train.py:21)."""
+    torch.manual_seed(42)
+    a = MultiTaskNet(21, 19, [32, 32])
+    torch.manual_seed(42)
+    b = MultiTaskNet(21, 19, [32, 32])
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    w = a.encoder.conv1.conv.weight
+    assert float(w.abs().max()) <= 1.0 / (27 ** 0.5) + 1e-6      # kaiming-uniform(a=sqrt 5) bound
+
+
+def test_cpu_without_extension_fails_loudly():
+    from hand_gesture_recognition_amd import lib
+    lib.use_library(lib.HIP_LIB) if os.path.exists(lib.HIP_LIB) else None
+    if not os.path.exists(lib.HIP_LIB):
+        pytest.skip("HIP library not built")
+    model = MultiTaskNet(21, 19, [32, 32])
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.gpu
+def test_config1_fp32_gpu(golden_dir):
+    """BASELINE config 1 (hagrid.yaml, 192x192, B=4) in fp32 validation mode: 1e-3."""
+    _run(Backend("hip"), "config1_b4_s192", golden_dir, torch.float32, 1e-3, 1e-3)
+
+
+@pytest.mark.gpu
+def test_config1_bf16_gpu(golden_dir):
+    _run(Backend("hip"), "config1_b4_s192", golden_dir, torch.bfloat16, 5e-2, 0.3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_b2_s64", "tiny_b3_s32"])
+def test_small_fp32_gpu(golden_dir, name):
+    _run(Backend("hip"), name, golden_dir, torch.float32, 1e-3, 1e-3)
