@@ -1,0 +1,186 @@
+"""bench.py -- images/sec of one MultiTaskNet training step (BASELINE.json metric).
+
+  python bench.py [--gpus N --steps K --warmup W]       (N > 1: launched by torch.distributed.run)
+
+A "step" = forward + 0.001*CE + JointsMSE + backward (+ RCCL gradient all-reduce) + AdamW on one
+synthetic batch already resident in HBM; workload = BASELINE.json configs[1]: MultiTaskNet
+(hagrid.yaml: 21 joints, 19 classes) 192x192, B=256 per GPU, bf16 storage / fp32 accumulate.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family: the MFMA implicit-GEMM
+`igemm_kernel<bf16,128,128>`, timed live with events on the launch stream in an extra
+instrumented step after the timed region) and `cpu_baseline` (the oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+TRAIN_GFLOP_PER_IMG = 13.09        # fwd + dgrad + wgrad @192^2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--size", type=int, default=192)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def igemm_roofline(step, batch):
+    """Time every launch of the dominant kernel family inside one real training step."""
+    from hand_gesture_recognition_amd import ops
+    rec = []
+
+    def big_tile(M, N):
+        return N % 128 == 0 and M >= 128 * 64
+
+    def wrap(name, fn, geom):
+        def inner(*a, **k):
+            info = geom(*a, **k)
+            if info is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                      # current stream == the stream the kernel is launched on
+            r = fn(*a, **k)
+            e1.record()
+            rec.append((name, info, e0, e1))
+            return r
+        return inner
+
+    def g_fwd(x, w, y, stats, k, s):
+        B, H, W, Cin = x.shape
+        Cout, M = y.shape[-1], y.numel() // y.shape[-1]
+        return (2.0 * M * Cout * k * k * Cin) if big_tile(M, Cout) else None
+
+    def g_dgrad(dy, wt, dx, res, k, s):
+        Cout, Min = dy.shape[-1], dx.numel() // dx.shape[-1]
+        Cin, Mout = dx.shape[-1], dy.numel() // dy.shape[-1]
+        return (2.0 * Mout * Cout * k * k * Cin) if big_tile(Min, Cin) else None
+
+    def g_lin(x, w, out, **kw):
+        K, N = x.shape[-1], out.shape[-1]
+        M = x.numel() // K
+        return (2.0 * M * N * K) if big_tile(M, N) else None
+
+    saved = (ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd)
+    ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = (wrap("conv_fwd", saved[0], g_fwd), wrap("conv_dgrad", saved[1], g_dgrad),
+                                                    wrap("linear", saved[2], g_lin))
+    try:
+        step._eager(*batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = saved
+    flops = sum(r[1] for r in rec)
+    secs = sum(r[2].elapsed_time(r[3]) for r in rec) * 1e-3
+    achieved = flops / secs / 1e12
+    return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,128,128,2,2>", "achieved": round(achieved, 1),
+            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None, "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
+            "flops_per_launch": flops / len(rec), "share_of_step_ms": round(secs * 1e3, 3)}
+
+
+def cpu_baseline(size):
+    """The oracle (CPU port of the reference path) timed on this box's host cores: B=16 train steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mtn_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 16
+    sd = O.synthetic_state_dict(21, 19, seed=0)
+    batch = O.synthetic_batch(B, size, seed=1234, gaussian_targets=False)
+    st = {}
+    O.train_step(sd, batch, st, 1e-3)                  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 3 or time.perf_counter() - t0 < 10.0:
+        O.train_step(sd, batch, st, 1e-3)
+        n += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps (fwd+loss+bwd+AdamW) at B={B}, {size}x{size}, fp32, oracle/mtn_oracle.py on torch-CPU"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+    from hand_gesture_recognition_amd.train import TrainStep, synthetic_batch
+
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(42)
+    model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=dt).to(dev)
+    step = TrainStep(model, a.batch, lr=1e-3, use_graph=bool(a.graph))
+    batch = synthetic_batch(a.batch, (a.size, a.size), 21, 19, dev, 1234 + rank)
+
+    for _ in range(a.warmup):
+        step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    loss_val = [float(x) for x in losses]
+    assert all(x == x and abs(x) < 1e6 for x in loss_val), f"non-finite losses {loss_val}"
+
+    roof = None
+    if not a.no_roofline and a.dtype == "bf16":
+        roof = igemm_roofline(step, batch)          # every rank runs it (the step holds a collective)
+    if rank == 0:
+        ips = world * a.batch * a.steps / elapsed
+        out = {
+            "metric": "images/sec training step, MultiTaskNet 192x192 B=256", "value": round(ips, 1),
+            "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"MultiTaskNet(21 joints, 19 classes) {a.size}x{a.size} train step "
+                                   f"(fwd + 0.001*CE + JointsMSE + bwd + AdamW), B={a.batch}/GPU, random-init weights",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "hipgraph": bool(a.graph)},
+            "algorithmic_tflops": round(ips * TRAIN_GFLOP_PER_IMG / 1e3, 1) if a.size == 192 else None,
+            "final_losses": [round(x, 6) for x in loss_val],
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+"""Training step + flag surface of the reference's ``train.py`` for the MI355X-native MultiTaskNet.
+
+What is mirrored (reference train.py): the loss recipe ``0.001 * CE + JointsMSE`` (:63-64,75),
+``AdamW(model.parameters(), lr)`` with PyTorch defaults (:50-51), ``MultiStepLR(lr_step,
+lr_factor)`` stepped per epoch (:53-56) and the argparse flags (:244-281).  Lightning, the HaGRID
+dataloader, TensorBoard and the CPU metrics are out of scope: the step consumes
+tensors that follow the batch contract of libs/load.py (img, label, target, target_weight).
+
+New surface (not in the reference, which is single-device): one process per GPU under
+``torchrun``; gradients live in ONE flat fp32 buffer that is all-reduced (RCCL over xGMI, sum) in
+a single bucket; the 1/world_size mean is folded into the fused AdamW kernel.  BatchNorm
+statistics stay per GPU (no SyncBN), so DDP parity is "mean of per-rank gradients".
+"""
+import argparse
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+from .multitasknet import MultiTaskNet
+
+
+# ------------------------------------------------------------------------------------------------
+# loss modules with the reference's interface (libs/loss.py)
+# ------------------------------------------------------------------------------------------------
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, hm, label, target, tw, ce_weight):
+        logits, hm = logits.contiguous().float(), hm.contiguous().float()
+        dl, dh = torch.empty_like(logits), torch.empty_like(hm)
+        part = torch.empty(ops.loss_partial_len(hm.numel()), dtype=torch.float32, device=hm.device)
+        losses = torch.empty(3, dtype=torch.float32, device=hm.device)
+        ops.loss_fwd_bwd(logits, label.contiguous(), hm, target.contiguous().float(),
+                         tw.contiguous().float(), dl, dh, part, losses, ce_weight)
+        ctx.save_for_backward(dl, dh)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, dh = ctx.saved_tensors
+        # d total = d(ce part) + d(joints part); losses = (total, ce, joints)
+        gl = (g[0] + g[1]) * dl
+        gh = (g[0] + g[2]) * dh
+        return gl, gh, None, None, None, None
+
+
+class MultiTaskCriterion(nn.Module):
+    """(total, class_loss, joints_loss) = (0.001*CE + JMSE, 0.001*CE, JMSE)  -- train.py:63-64,75."""
+
+    def __init__(self, class_weight=0.001):
+        super().__init__()
+        self.class_weight = class_weight
+
+    def forward(self, pred_label, heatmap, label, target, target_weight):
+        losses = _FusedLoss.apply(pred_label, heatmap, label, target, target_weight, self.class_weight)
+        return losses[0], losses[1], losses[2]
+
+
+class JointsMSELoss(nn.Module):
+    """libs/loss.py:4-30 (use_target_weight=True): 0.5 * mean((w (p - t))^2)."""
+
+    def __init__(self, use_target_weight=True):
+        super().__init__()
+        if not use_target_weight:
+            raise NotImplementedError("the reference trains with use_target_weight=True (train.py:35)")
+
+    def forward(self, output, target, target_weight):
+        B = output.shape[0]
+        logits = torch.zeros(B, 1, device=output.device)
+        label = torch.zeros(B, dtype=torch.int64, device=output.device)
+        return _FusedLoss.apply(logits, output, label, target, target_weight, 0.0)[2]
+
+
+class ClassificationLoss(nn.Module):
+    """libs/loss.py:33-40: CrossEntropyLoss(reduction='mean')."""
+
+    def forward(self, output, target):
+        B = output.shape[0]
+        z = torch.zeros(B, 1, 1, 1, device=output.device)
+        return _FusedLoss.apply(output, z, target, z, torch.zeros(B, 1, 1, device=output.device), 1.0)[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# fused training step
+# ------------------------------------------------------------------------------------------------
+class TrainStep:
+    """forward + loss + backward (+ gradient all-reduce) + AdamW as one device-side sequence.
+
+    No host synchronisation inside ``__call__``: the returned losses tensor is device resident.
+    With ``use_graph`` the whole step is captured once into a hipGraph and replayed.
+    """
+
+    def __init__(self, model: MultiTaskNet, batch_size, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.01, lr_step=(30, 40), lr_factor=0.1, process_group=None,
+                 use_graph=False, want_attn=True):
+        self.model, self.B = model, int(batch_size)
+        self.eng = model.engine(self.B)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        dev = model.flat_params.device
+        self.m = torch.zeros_like(model.flat_params)
+        self.v = torch.zeros_like(model.flat_params)
+        self.state = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.state[:5] = torch.tensor([lr, betas[0], betas[1], eps, weight_decay])
+        self.state[8] = 1.0 / self.world
+        self.base_lr, self.lr_step, self.lr_factor, self.epoch = lr, tuple(lr_step), lr_factor, 0
+        self.want_attn = want_attn
+        self.use_graph, self._graph, self._static = use_graph, None, None
+        if self.world > 1:
+            dist.broadcast(model.flat_params, src=0, group=process_group)   # identical replicas
+        model.train()
+
+    # -- schedule (MultiStepLR stepped once per epoch, train.py:53-56) -----------------------------
+    def epoch_end(self):
+        self.epoch += 1
+        lr = self.base_lr * (self.lr_factor ** sum(1 for ms in self.lr_step if self.epoch >= ms))
+        self.state[0:1].fill_(lr)
+        return lr
+
+    def _fwd_bwd(self, img, label, target, tw):
+        e = self.eng
+        e.forward(img, training=True, want_attn=self.want_attn)
+        e.loss(label, target, tw, with_grads=True)
+        e.backward()
+
+    def _update(self):
+        mdl = self.model
+        ops.adamw_step(mdl.flat_params, mdl.flat_grads, self.m, self.v, self.state)
+
+    def _eager(self, img, label, target, tw):
+        self._fwd_bwd(img, label, target, tw)
+        if self.world > 1:
+            dist.all_reduce(self.model.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+        self._update()
+        return self.eng.losses
+
+    def _capture(self, img, label, target, tw):
+        self._static = [t.clone() for t in (img, label, target, tw)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):            # warm-up outside capture (lazy kernel attributes etc.)
+            self._eager(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._fwd_bwd(*self._static)
+                self._update()
+            self._graph = (g,)
+        else:                                   # RCCL all-reduce stays outside the graphs
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._fwd_bwd(*self._static)
+            with torch.cuda.graph(g2):
+                self._update()
+            self._graph = (g1, g2)
+
+    def __call__(self, img, label, target, target_weight):
+        if not (self.use_graph and img.is_cuda):
+            return self._eager(img, label, target, target_weight)
+        if self._graph is None:
+            self._capture(img, label, target, target_weight)
+        for dst, src in zip(self._static, (img, label, target, target_weight)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self._graph[0].replay()
+        if self.world > 1:
+            dist.all_reduce(self.model.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+            self._graph[1].replay()
+        return self.eng.losses
+
+    # -- optimizer state for checkpoints ------------------------------------------------------------
+    def state_dict(self):
+        return {"exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "state": self.state.clone(),
+                "epoch": self.epoch}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"]); self.state.copy_(sd["state"])
+        self.epoch = int(sd["epoch"])
+
+
+def synthetic_batch(batch, image_size, num_joints, num_classes, device, seed):
+    """Synthetic stand-in for the dataloader contract."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    S = image_size
+    img = torch.randn(batch, 3, S[0], S[1], generator=g)
+    label = torch.randint(0, num_classes, (batch,), generator=g)
+    target = torch.rand(batch, num_joints, S[0] // 4, S[1] // 4, generator=g)
+    tw = torch.ones(batch, num_joints, 1)
+    return tuple(t.to(device) for t in (img, label, target, tw))
+
+
+def build_parser():
+    """The reference's flag surface (train.py:244-281) plus --devices / --steps for synthetic runs."""
+    p = argparse.ArgumentParser(description="MI355X-native MultiTaskNet training (synthetic data)")
+    p.add_argument("--data_config", type=str, default=None, help="YAML with num_joints / num_classes")
+    p.add_argument("--suffix", type=str, default="run")
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--devices", type=int, default=1, help="number of GPUs (launch with torchrun)")
+    p.add_argument("--backbone", type=str, default="gelans")
+    p.add_argument("--batch_size", type=int, default=32)
+    p.add_argument("--epochs", type=int, default=50)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--lr_step", type=int, nargs="+", default=[30, 40])
+    p.add_argument("--lr_factor", type=float, default=0.1)
+    p.add_argument("--image_size", type=int, nargs=2, default=[192, 192])
+    p.add_argument("--sigma", type=int, default=2)
+    p.add_argument("--log_dir", type=str, default="logs")
+    p.add_argument("--save_dir", type=str, default="output")
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--steps_per_epoch", type=int, default=10, help="synthetic steps per epoch")
+    p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32"])
+    return p
+
+
+def run(args, data_cfg):
+    import os
+    assert args.image_size[0] == args.image_size[1], "only square images are supported"   # train.py:191-192
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(args.device)))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    torch.manual_seed(42)                                                                 # train.py:21
+    dt = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    model = MultiTaskNet(data_cfg["num_joints"], data_cfg["num_classes"], args.image_size, compute_dtype=dt).cuda()
+    step = TrainStep(model, args.batch_size, lr=args.lr, lr_step=args.lr_step, lr_factor=args.lr_factor)
+    rank = dist.get_rank() if world > 1 else 0
+    batch = synthetic_batch(args.batch_size, args.image_size, data_cfg["num_joints"], data_cfg["num_classes"],
+                            torch.device("cuda", local), 1234 + rank)
+    for epoch in range(args.epochs):
+        for _ in range(args.steps_per_epoch):
+            losses = step(*batch)
+        lr = step.epoch_end()
+        if rank == 0:
+            t, c, j = (float(x) for x in losses)
+            print(f"epoch {epoch}: total {t:.6f} class {c:.6f} joints {j:.6f} lr {lr:g}", flush=True)
+    return model
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    cfg = {"num_joints": 21, "num_classes": 19}
+    if args.data_config:
+        import yaml
+        with open(args.data_config) as f:
+            y = yaml.safe_load(f)
+        cfg = {"num_joints": y["num_joints"], "num_classes": y["num_classes"]}
+    run(args, cfg)
+
+
+if __name__ == "__main__":
+    main()

@@ -121,3 +121,62 @@ def test_config1_bf16_gpu(golden_dir):
 @pytest.mark.parametrize("name", ["small_b2_s64", "tiny_b3_s32"])
 def test_small_fp32_gpu(golden_dir, name):
     _run(Backend("hip"), name, golden_dir, torch.float32, 1e-3, 1e-3)
+
+
+def _train_steps(be, name, golden_dir, dtype, nsteps, tol_w, use_graph=False):
+    from hand_gesture_recognition_amd.train import TrainStep
+    g, sd, batch, model = _setup(be, name, golden_dir, dtype)
+    dev_batch = tuple(t.to(be.device) for t in batch)
+    step = TrainStep(model, batch[0].shape[0], lr=float(g["lr"]), use_graph=use_graph)
+    sd_o, st = {k: v.clone() for k, v in sd.items()}, {}
+    for i in range(nsteps):
+        losses = step(*dev_batch)
+        (_, _, _), ref_losses, _ = O.train_step(sd_o, batch, st, float(g["lr"]))
+        be.sync()
+        assert rel_err(losses, torch.stack(ref_losses)) < tol_w, (i, losses, ref_losses)
+    # Adam normalises every element by |g|, so elements whose gradient is ~0 can flip the sign of
+    # their update under ANY change of summation order: compare element-wise with a budget
+    # (>= 99.5 % of the elements within 10 % of one lr step) and the tensors by norm.
+    lr = float(g["lr"])
+    bad = tot = 0
+    for k, p in model.named_parameters():
+        d = (p.detach().cpu() - sd_o[k]).abs()
+        bad += int((d > 0.1 * lr * nsteps).sum())
+        tot += d.numel()
+        assert abs(float(p.double().norm()) / float(sd_o[k].double().norm()) - 1) < 1e-4, k
+    assert bad / tot < 5e-3, (bad, tot)
+    if nsteps == 1:
+        names = [str(n) for n in g["param_names"]]
+        wn = torch.tensor([float(dict(model.named_parameters())[k].double().norm()) for k in names])
+        assert rel_err(wn, torch.from_numpy(g["step_weight_norms"])) < tol_w
+    return model
+
+
+def test_train_step_fp32_emu(golden_dir):
+    """forward + loss + backward + fused AdamW vs the oracle's train step (weights after the step)."""
+    _train_steps(Backend("emu"), "tiny_b3_s32", golden_dir, torch.float32, 1, 1e-3)
+
+
+@pytest.mark.gpu
+def test_train_steps_fp32_gpu(golden_dir):
+    _train_steps(Backend("hip"), "config1_b4_s192", golden_dir, torch.float32, 1, 1e-3)
+    _train_steps(Backend("hip"), "small_b2_s64", golden_dir, torch.float32, 3, 2e-3)
+
+
+@pytest.mark.gpu
+def test_train_steps_graph_gpu(golden_dir):
+    """the hipGraph replay path gives the same step as the eager one"""
+    _train_steps(Backend("hip"), "small_b2_s64", golden_dir, torch.float32, 3, 2e-3, use_graph=True)
+
+
+@pytest.mark.gpu
+def test_eval_mode_gpu(golden_dir):
+    """model.eval(): BatchNorm uses running statistics (export.py:41), no state is mutated."""
+    be = Backend("hip")
+    g, sd, batch, model = _setup(be, "small_b2_s64", golden_dir, torch.float32)
+    model.eval()
+    with torch.no_grad():
+        cls_out, hmap, attn = model(batch[0].to(be.device))
+    ref = O.multitasknet_forward(batch[0], {k: v.clone() for k, v in sd.items()}, training=False)
+    assert rel_err(cls_out, ref[0]) < 1e-3 and rel_err(hmap, ref[1]) < 1e-3 and rel_err(attn, ref[2]) < 1e-3
+    assert all(int(v) == 0 for k, v in model.state_dict().items() if k.endswith("num_batches_tracked"))
