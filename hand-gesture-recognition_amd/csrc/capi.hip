@@ -63,6 +63,7 @@ int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
     p.mul = 1; p.sgn = -1; p.off = pad; p.div = stride;
     p.M = B * H * W; p.N = Cin; p.K = ksize * ksize * Cout;
     p.res = res; p.ldr = ldres;
+    p.pm = (stride == 2 && ksize == 3 && H % 2 == 0 && W % 2 == 0) ? 1 : 0;
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
@@ -219,9 +220,9 @@ int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float*
                       void* stream) {
     return mtn_pose_fwd_run(tok, W, bias, hm, dtype, B, h, w, J, (hipStream_t)stream);
 }
-int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW, float* dbias, float* slab,
+int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                       int dtype, int B, int h, int w, int J, void* stream) {
-    return mtn_pose_bwd_run(tok, W, dhm, dtok, dW, dbias, slab, dtype, B, h, w, J, (hipStream_t)stream);
+    return mtn_pose_bwd_run(tok, W, dhm, dtok, dW_dbias, slab, dtype, B, h, w, J, (hipStream_t)stream);
 }
 int mtn_loss_partial_len(long long n) { return mtn_loss_blocks((long)n); }
 int mtn_loss_fwd_bwd(const float* logits, const long long* label, const float* hm, const float* target,

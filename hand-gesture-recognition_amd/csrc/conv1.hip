@@ -11,57 +11,97 @@ namespace {
 constexpr int CO = 64, KK = 27, PXB = 256;    // output channels, taps*cin, pixels per block
 
 // y[m][64] = sum_{kh,kw,ci} x[b][ci][2oy-1+kh][2ox-1+kw] * w[co][kh][kw][ci]; stats[tile][2][64]
+// As a GEMM: M = 256 output pixels per workgroup, N = 64, K = 27 zero-padded to 32 (one bf16 MFMA
+// K step).  Each thread gathers the 27-tap patch of ITS pixel from the NCHW image (lanes walk
+// along ox: stride-2 fp32 reads), packs it to T and writes one padded LDS row; the weight
+// matrix is 64 x 32 in LDS.  The C tile is staged through LDS in T so the 32 KB of NHWC output
+// of a workgroup is one fully coalesced block of 16-byte stores and the BN partial statistics
+// are column sums of exactly the stored values.
 template <class T>
 __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
                                                         T* __restrict__ y, float* __restrict__ stats, int B, int H,
                                                         int W, int OH, int OW) {
     constexpr int VEC = 16 / (int)sizeof(T);
-    __shared__ float sw[KK][CO];                 // weights, tap-major
-    __shared__ float st[PXB][CO + 1];            // output tile for the statistics
-    const int tid = threadIdx.x;
-    for (int i = tid; i < KK * CO; i += PXB) {
-        const int co = i / KK, k = i - co * KK;
-        sw[k][co] = to_f<T>(w[i]);
+    constexpr int KP = 32;                                   // padded K
+    constexpr int PA = KP + 16 / (int)sizeof(T);             // LDS pitch of A / W rows (elements)
+    constexpr int PC = CO + 16 / (int)sizeof(T);             // LDS pitch of the C tile (elements)
+    constexpr int KI = Mma<T>::KI;
+    MTN_DYN_SMEM(smem);
+    T* sA = reinterpret_cast<T*>(smem);                      // [256][PA]
+    T* sB = sA + PXB * PA;                                   // [64][PA]
+    T* sC = reinterpret_cast<T*>(smem);                      // [256][PC] (after the MFMAs)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // weights: thread -> (row n = tid/4, 8 consecutive k)
+    {
+        const int n = tid >> 2, k0 = (tid & 3) * 8;
+        float v[8];
+        MTN_UNROLL for (int e = 0; e < 8; ++e) v[e] = (k0 + e < KK) ? to_f<T>(w[n * KK + k0 + e]) : 0.f;
+        MTN_UNROLL for (int c = 0; c < 8; c += VEC) *reinterpret_cast<chunk16*>(sB + n * PA + k0 + c) = pack<T>(v + c);
     }
-    __syncthreads();
     const long M = (long)B * OH * OW;
     const long m = (long)blockIdx.x * PXB + tid;
-    float acc[CO];
-    MTN_UNROLL for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    if (m < M) {
-        const int ohw = OH * OW;
-        const int b = (int)(m / ohw), rem = (int)(m - (long)b * ohw);
-        const int oy = rem / OW, ox = rem - oy * OW;
-        const float* xb = x + (long)b * 3 * H * W;
-        MTN_UNROLL for (int kh = 0; kh < 3; ++kh) {
-            const int iy = 2 * oy - 1 + kh;
-            MTN_UNROLL for (int kw = 0; kw < 3; ++kw) {
-                const int ix = 2 * ox - 1 + kw;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                MTN_UNROLL for (int ci = 0; ci < 3; ++ci) {
-                    const float xv = ok ? xb[((long)ci * H + iy) * W + ix] : 0.f;
-                    const float* wr = sw[(kh * 3 + kw) * 3 + ci];
-                    MTN_UNROLL for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
+    {
+        float v[KP];
+        MTN_UNROLL for (int k = 0; k < KP; ++k) v[k] = 0.f;
+        if (m < M) {
+            const int ohw = OH * OW;
+            const int b = (int)(m / ohw), rem = (int)(m - (long)b * ohw);
+            const int oy = rem / OW, ox = rem - oy * OW;
+            const float* xb = x + (long)b * 3 * H * W;
+            MTN_UNROLL for (int kh = 0; kh < 3; ++kh) {
+                const int iy = 2 * oy - 1 + kh;
+                MTN_UNROLL for (int kw = 0; kw < 3; ++kw) {
+                    const int ix = 2 * ox - 1 + kw;
+                    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    MTN_UNROLL for (int ci = 0; ci < 3; ++ci)
+                        v[(kh * 3 + kw) * 3 + ci] = ok ? xb[((long)ci * H + iy) * W + ix] : 0.f;
                 }
             }
         }
-        MTN_UNROLL for (int c0 = 0; c0 < CO; c0 += VEC)
-            *reinterpret_cast<chunk16*>(y + m * CO + c0) = pack<T>(acc + c0);
+        MTN_UNROLL for (int c = 0; c < KP; c += VEC) *reinterpret_cast<chunk16*>(sA + tid * PA + c) = pack<T>(v + c);
+    }
+    __syncthreads();
+    f32x4_t acc[4][4];
+    MTN_UNROLL for (int i = 0; i < 4; ++i)
+        MTN_UNROLL for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+    {
+        const T* a = sA + (wid * 64 + (lane & 15)) * PA + (lane >> 4) * (KI / 4);
+        const T* bq = sB + (lane & 15) * PA + (lane >> 4) * (KI / 4);
+        MTN_UNROLL for (int ks = 0; ks < KP / KI; ++ks) {
+            typename Mma<T>::Frag fa[4], fb[4];
+            MTN_UNROLL for (int i = 0; i < 4; ++i) fa[i] = Mma<T>::load(a + i * 16 * PA + ks * KI);
+            MTN_UNROLL for (int j = 0; j < 4; ++j) fb[j] = Mma<T>::load(bq + j * 16 * PA + ks * KI);
+            MTN_UNROLL for (int i = 0; i < 4; ++i)
+                MTN_UNROLL for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        }
+    }
+    __syncthreads();
+    MTN_UNROLL for (int i = 0; i < 4; ++i)
+        MTN_UNROLL for (int j = 0; j < 4; ++j)
+            MTN_UNROLL for (int r = 0; r < 4; ++r)
+                sC[(wid * 64 + i * 16 + 4 * (lane >> 4) + r) * PC + j * 16 + (lane & 15)] = from_f<T>(acc[i][j][r]);
+    __syncthreads();
+    constexpr int CPR = CO / VEC;
+    for (int idx = tid; idx < PXB * CPR; idx += PXB) {
+        const int row = idx / CPR, col = (idx - row * CPR) * VEC;
+        const long mm = (long)blockIdx.x * PXB + row;
+        if (mm < M) *reinterpret_cast<chunk16*>(y + mm * CO + col) = *reinterpret_cast<const chunk16*>(sC + row * PC + col);
     }
     if (stats) {
-        MTN_UNROLL for (int c = 0; c < CO; ++c) st[tid][c] = (m < M) ? round_to<T>(acc[c]) : 0.f;
-        __syncthreads();
         const int c = tid & 63, part = tid >> 6;
         float s = 0.f, ss = 0.f;
-        for (int r = part * 64; r < part * 64 + 64; ++r) { const float v = st[r][c]; s += v; ss += v * v; }
+        long rows = M - (long)blockIdx.x * PXB;
+        if (rows > PXB) rows = PXB;
+        for (int r = part * 64; r < part * 64 + 64 && r < rows; ++r) { const float v = to_f<T>(sC[r * PC + c]); s += v; ss += v * v; }
         __syncthreads();
-        st[part][c] = s;
-        st[4 + part][c] = ss;
+        float* red = reinterpret_cast<float*>(smem);         // [2][4][64]
+        red[part * 64 + c] = s;
+        red[256 + part * 64 + c] = ss;
         __syncthreads();
         if (tid < 128) {
             const int which = tid >> 6;
-            const float t = st[which * 4 + 0][c] + st[which * 4 + 1][c] + st[which * 4 + 2][c] + st[which * 4 + 3][c];
-            stats[((long)blockIdx.x * 2 + which) * CO + c] = t;
+            const float* q = red + which * 256 + c;
+            stats[((long)blockIdx.x * 2 + which) * CO + c] = q[0] + q[64] + q[128] + q[192];
         }
     }
 }
@@ -131,12 +171,19 @@ int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int 
     const long M = (long)B * OH * OW;
     MTN_REQUIRE(M * CO < (1L << 31), "conv1_fwd: tensor too large");
     const int blocks = mtn_conv1_tiles(M);
-    if (dtype == MTN_BF16)
-        MTN_LAUNCH(conv1_fwd_kernel<bf16_t>, dim3(blocks), dim3(PXB), 0, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
+    if (dtype == MTN_BF16) {
+        const size_t lds = (size_t)PXB * (CO + 8) * 2;       // C tile (bf16) >= A + W tiles
+        MTN_LAUNCH(conv1_fwd_kernel<bf16_t>, dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
                    H, W, OH, OW);
-    else
-        MTN_LAUNCH(conv1_fwd_kernel<float>, dim3(blocks), dim3(PXB), 0, stream, x, (const float*)w, (float*)y, stats, B, H,
+    } else {
+        const size_t lds = (size_t)PXB * (CO + 4) * 4;
+#ifndef MTN_EMU
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+#endif
+        MTN_LAUNCH(conv1_fwd_kernel<float>, dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
                    W, OH, OW);
+    }
     return mtn_check_launch("conv1_fwd");
 }
 

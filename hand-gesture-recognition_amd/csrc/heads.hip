@@ -32,23 +32,31 @@ __device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
 }
 
 constexpr int TP = 8;                 // output tile edge
-constexpr int UP = DIM + 4;           // LDS pitch of the feature tile (floats)
 
+// Forward: a workgroup owns an 8x8 tile of output pixels of one image.  Phase 1 (VALU) builds
+// U[64 px][256] = ReLU(bilinear(tokens)) in LDS in T; phase 2 contracts it with W (J x 256, padded
+// to 32 rows, T) on MFMA: M = 64 pixels (one 16-row tile per wave), N = 32, K = 256.
 template <class T>
 __global__ __launch_bounds__(256) void pose_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                        const float* __restrict__ bias, float* __restrict__ hm, int h, int w,
                                                        int J) {
+    constexpr int PU = DIM + 16 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
     MTN_DYN_SMEM(smem);
-    float* sU = reinterpret_cast<float*>(smem);         // [64][UP]
-    float* sW = sU + TP * TP * UP;                      // [J][DIM]
+    T* sU = reinterpret_cast<T*>(smem);                 // [64][PU]
+    T* sW = sU + TP * TP * PU;                          // [32][PU]
     const int OH = 4 * h, OW = 4 * w;
     const int tiles_x = (OW + TP - 1) / TP;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
-    for (int i = tid; i < J * DIM; i += 256) sW[i] = W[i];
-    // phase 1: interpolate + ReLU; thread = (pixel lane, 4 channels)
-    {
+    for (int i = tid; i < 32 * (DIM / 4); i += 256) {
+        const int j = i / (DIM / 4), c = (i - j * (DIM / 4)) * 4;
+        float v[4];
+        MTN_UNROLL for (int e = 0; e < 4; ++e) v[e] = j < J ? W[j * DIM + c + e] : 0.f;
+        MTN_UNROLL for (int e = 0; e < 4; ++e) sW[j * PU + c + e] = from_f<T>(v[e]);
+    }
+    {   // phase 1: thread = (pixel lane, 4 channels)
         const int cg = tid & 63, pq = tid >> 6;
         const T* base = tok + ((long)b * (h * w + 1) + 1) * DIM + cg * 4;
         for (int px = pq; px < TP * TP; px += 4) {
@@ -56,60 +64,59 @@ __global__ __launch_bounds__(256) void pose_fwd_kernel(const T* __restrict__ tok
             float u[4] = {0.f, 0.f, 0.f, 0.f};
             if (oy < OH && ox < OW) {
                 const Lerp ly = lerp_coord(oy, h, OH), lx = lerp_coord(ox, w, OW);
-                {
-                    float t0[4], t1[4], t2[4], t3[4];
-                    const T* p00 = base + (long)(ly.i0 * w + lx.i0) * DIM;
-                    const T* p01 = base + (long)(ly.i0 * w + lx.i1) * DIM;
-                    const T* p10 = base + (long)(ly.i1 * w + lx.i0) * DIM;
-                    const T* p11 = base + (long)(ly.i1 * w + lx.i1) * DIM;
-                    MTN_UNROLL for (int e = 0; e < 4; ++e) {
-                        t0[e] = to_f<T>(p00[e]); t1[e] = to_f<T>(p01[e]); t2[e] = to_f<T>(p10[e]); t3[e] = to_f<T>(p11[e]);
-                    }
-                    const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
-                    MTN_UNROLL for (int e = 0; e < 4; ++e) {
-                        const float v = wy0 * (wx0 * t0[e] + lx.w1 * t1[e]) + ly.w1 * (wx0 * t2[e] + lx.w1 * t3[e]);
-                        u[e] = v > 0.f ? v : 0.f;
-                    }
+                float t0[4], t1[4], t2[4], t3[4];
+                const T* p00 = base + (long)(ly.i0 * w + lx.i0) * DIM;
+                const T* p01 = base + (long)(ly.i0 * w + lx.i1) * DIM;
+                const T* p10 = base + (long)(ly.i1 * w + lx.i0) * DIM;
+                const T* p11 = base + (long)(ly.i1 * w + lx.i1) * DIM;
+                MTN_UNROLL for (int e = 0; e < 4; ++e) {
+                    t0[e] = to_f<T>(p00[e]); t1[e] = to_f<T>(p01[e]); t2[e] = to_f<T>(p10[e]); t3[e] = to_f<T>(p11[e]);
+                }
+                const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
+                MTN_UNROLL for (int e = 0; e < 4; ++e) {
+                    const float v = wy0 * (wx0 * t0[e] + lx.w1 * t1[e]) + ly.w1 * (wx0 * t2[e] + lx.w1 * t3[e]);
+                    u[e] = v > 0.f ? v : 0.f;
                 }
             }
-            *reinterpret_cast<float4*>(sU + px * UP + cg * 4) = make_float4(u[0], u[1], u[2], u[3]);
+            MTN_UNROLL for (int e = 0; e < 4; ++e) sU[px * PU + cg * 4 + e] = from_f<T>(u[e]);
         }
     }
     __syncthreads();
-    // phase 2: thread = (pixel, joint group); joints jg, jg+4, ...
-    const int px = tid & 63, jg = tid >> 6;
-    float acc[MAXJ / 4];
-    MTN_UNROLL for (int q = 0; q < MAXJ / 4; ++q) acc[q] = 0.f;
-    for (int c = 0; c < DIM; c += 4) {
-        const float4 uv = *reinterpret_cast<const float4*>(sU + px * UP + c);
-        MTN_UNROLL for (int q = 0; q < MAXJ / 4; ++q) {
-            const int j = jg + 4 * q;
-            if (j < J) {
-                const float4 wv = *reinterpret_cast<const float4*>(sW + j * DIM + c);
-                acc[q] += uv.x * wv.x + uv.y * wv.y + uv.z * wv.z + uv.w * wv.w;
-            }
-        }
+    // phase 2: wave w -> pixels 16w..16w+15, joints 0..31
+    const int lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    f32x4_t a0 = zero4(), a1 = zero4();
+    const T* ap = sU + (wid * 16 + li) * PU + g * (KI / 4);
+    const T* bp = sW + li * PU + g * (KI / 4);
+    MTN_UNROLL for (int ks = 0; ks < DIM / KI; ++ks) {
+        const typename Mma<T>::Frag fa = Mma<T>::load(ap + ks * KI);
+        a0 = Mma<T>::mma(fa, Mma<T>::load(bp + ks * KI), a0);
+        a1 = Mma<T>::mma(fa, Mma<T>::load(bp + 16 * PU + ks * KI), a1);
     }
-    const int oy = ty * TP + px / TP, ox = tx * TP + px % TP;
-    if (oy < OH && ox < OW) {
-        MTN_UNROLL for (int q = 0; q < MAXJ / 4; ++q) {
-            const int j = jg + 4 * q;
-            if (j < J) hm[(((long)b * J + j) * OH + oy) * OW + ox] = acc[q] + bias[j];
+    MTN_UNROLL for (int r = 0; r < 4; ++r) {
+        const int px = wid * 16 + 4 * g + r;
+        const int oy = ty * TP + px / TP, ox = tx * TP + px % TP;
+        if (oy < OH && ox < OW) {
+            if (li < J) hm[(((long)b * J + li) * OH + oy) * OW + ox] = a0[r] + bias[li];
+            if (16 + li < J) hm[(((long)b * J + 16 + li) * OH + oy) * OW + ox] = a1[r] + bias[16 + li];
         }
     }
 }
 
-// block = (channel chunk of CC, image b); threads = CC channels x (256/CC) pixel lanes
-template <class T, int CC>
+// Backward.  block = (channel chunk of CC, image b); threads = CC channels x PL pixel lanes.  The
+// image's heat-map gradient is streamed through LDS in chunks of PXC pixels (coalesced loads); each
+// thread recomputes u for its channel, forms g = sum_j d[j]*W[j][c], accumulates dW[j][c] in
+// registers and scatters g through the transposed bilinear stencil into an LDS token-gradient tile
+// (ds_add_f32: lanes of a wave hit consecutive banks).  slab row b = [dW (J*256) | dbias (J)].
+constexpr int CC = 32, PL = 256 / CC, PXC = 256;
+template <class T>
 __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                        const float* __restrict__ dhm, T* __restrict__ dtok,
-                                                       float* __restrict__ dWslab, int h, int w, int J) {
-    constexpr int PL = 256 / CC;
+                                                       float* __restrict__ slab, int h, int w, int J) {
     MTN_DYN_SMEM(smem);
-    const int hw = h * w, OH = 4 * h, OW = 4 * w;
+    const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW;
     float* sS = reinterpret_cast<float*>(smem);         // source tokens [hw][CC]
     float* sG = sS + hw * CC;                           // token-gradient accumulator [hw][CC]
-    float* sR = sG + hw * CC;                           // [PL][J][CC] dW reduction
+    float* sD = sG + hw * CC;                           // [J][PXC] chunk of dhm; later [PL][J][CC] / [4][J]
     const int b = blockIdx.y, c0 = blockIdx.x * CC;
     const int c = threadIdx.x % CC, pl = threadIdx.x / CC;
     const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + c0;
@@ -118,63 +125,73 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
         sS[i] = to_f<T>(base[(long)p * DIM + cc]);
         sG[i] = 0.f;
     }
-    float wj[MAXJ], dw[MAXJ];
-    MTN_UNROLL for (int j = 0; j < MAXJ; ++j) { wj[j] = j < J ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; }
-    __syncthreads();
-    const float* dh = dhm + (long)b * J * OH * OW;
-    for (int px = pl; px < OH * OW; px += PL) {
-        const int oy = px / OW, ox = px - oy * OW;
-        const Lerp ly = lerp_coord(oy, h, OH), lx = lerp_coord(ox, w, OW);
-        const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
-        const int i00 = (ly.i0 * w + lx.i0) * CC + c, i01 = (ly.i0 * w + lx.i1) * CC + c;
-        const int i10 = (ly.i1 * w + lx.i0) * CC + c, i11 = (ly.i1 * w + lx.i1) * CC + c;
-        const float v = wy0 * (wx0 * sS[i00] + lx.w1 * sS[i01]) + ly.w1 * (wx0 * sS[i10] + lx.w1 * sS[i11]);
-        const float u = v > 0.f ? v : 0.f;
-        float g = 0.f;
-        MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
-            if (j < J) {
-                const float d = dh[(long)j * OH * OW + px];
-                g += d * wj[j];
-                dw[j] += d * u;
+    float wj[MAXJ], dw[MAXJ], db[MAXJ];
+    MTN_UNROLL for (int j = 0; j < MAXJ; ++j) { wj[j] = j < J ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; db[j] = 0.f; }
+    const float* dh = dhm + (long)b * J * OHW;
+    const bool do_bias = blockIdx.x == 0;
+    for (int pb = 0; pb < OHW; pb += PXC) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < J * PXC; i += 256) {
+            const int j = i / PXC, p = i - j * PXC;
+            sD[i] = (pb + p < OHW) ? dh[(long)j * OHW + pb + p] : 0.f;
+        }
+        __syncthreads();
+        if (do_bias) {
+            MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
+                if (j < J) db[j] += sD[j * PXC + threadIdx.x];
+        }
+        for (int pp = pl; pp < PXC && pb + pp < OHW; pp += PL) {
+            const int px = pb + pp;
+            const int oy = px / OW, ox = px - oy * OW;
+            const Lerp ly = lerp_coord(oy, h, OH), lx = lerp_coord(ox, w, OW);
+            const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
+            const int i00 = (ly.i0 * w + lx.i0) * CC + c, i01 = (ly.i0 * w + lx.i1) * CC + c;
+            const int i10 = (ly.i1 * w + lx.i0) * CC + c, i11 = (ly.i1 * w + lx.i1) * CC + c;
+            const float v = wy0 * (wx0 * sS[i00] + lx.w1 * sS[i01]) + ly.w1 * (wx0 * sS[i10] + lx.w1 * sS[i11]);
+            const float u = v > 0.f ? v : 0.f;
+            float gsum = 0.f;
+            MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
+                if (j < J) {
+                    const float d = sD[j * PXC + pp];
+                    gsum += d * wj[j];
+                    dw[j] += d * u;
+                }
+            }
+            if (v > 0.f) {
+                atomicAdd(&sG[i00], gsum * wy0 * wx0);
+                atomicAdd(&sG[i01], gsum * wy0 * lx.w1);
+                atomicAdd(&sG[i10], gsum * ly.w1 * wx0);
+                atomicAdd(&sG[i11], gsum * ly.w1 * lx.w1);
             }
         }
-        if (v > 0.f) {
-            atomicAdd(&sG[i00], g * wy0 * wx0);
-            atomicAdd(&sG[i01], g * wy0 * lx.w1);
-            atomicAdd(&sG[i10], g * ly.w1 * wx0);
-            atomicAdd(&sG[i11], g * ly.w1 * lx.w1);
-        }
     }
+    __syncthreads();
     MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
-        if (j < J) sR[(pl * J + j) * CC + c] = dw[j];
+        if (j < J) sD[(pl * J + j) * CC + c] = dw[j];
     __syncthreads();
     for (int i = threadIdx.x; i < hw * CC; i += 256) {
         const int p = i / CC, cc = i - p * CC;
         dtok[((long)b * (hw + 1) + 1 + p) * DIM + c0 + cc] = from_f<T>(sG[i]);
     }
+    float* row = slab + (long)b * J * (DIM + 1);
     for (int i = threadIdx.x; i < J * CC; i += 256) {
         const int j = i / CC, cc = i - j * CC;
         float s = 0.f;
-        for (int q = 0; q < PL; ++q) s += sR[(q * J + j) * CC + cc];
-        dWslab[((long)b * J + j) * DIM + c0 + cc] = s;
+        for (int q = 0; q < PL; ++q) s += sD[(q * J + j) * CC + cc];
+        row[j * DIM + c0 + cc] = s;
     }
-}
-
-// dbias[j] = sum_{b,p} dhm[b][j][p]     (one block per joint)
-__global__ __launch_bounds__(256) void pose_bias_grad_kernel(const float* __restrict__ dhm, float* __restrict__ dbias, int B,
-                                                             int J, int HW) {
-    __shared__ float red[256];
-    const int j = blockIdx.x;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b)
-        for (int p = threadIdx.x; p < HW; p += 256) s += dhm[((long)b * J + j) * HW + p];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    if (do_bias) {
         __syncthreads();
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
+            if (j < J) {
+                const float t = wave_sum(db[j]);
+                if (lane == 0) sD[wid * J + j] = t;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < J) row[J * DIM + threadIdx.x] = sD[threadIdx.x] + sD[J + threadIdx.x] + sD[2 * J + threadIdx.x] + sD[3 * J + threadIdx.x];
     }
-    if (threadIdx.x == 0) dbias[j] = red[0];
 }
 
 // ---- loss ------------------------------------------------------------------------------------------
@@ -244,12 +261,15 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_fwd: bad sizes (J=%d, max %d)", J, MAXJ);
     const int OH = 4 * h, OW = 4 * w;
     const dim3 grid(mtn_cdiv(OH, TP) * mtn_cdiv(OW, TP), B);
-    const size_t lds = (size_t)(TP * TP * UP + J * DIM) * sizeof(float);
+    const size_t esz = dtype == MTN_BF16 ? 2 : 4;
+    const size_t lds = (size_t)(TP * TP + 32) * (DIM * esz + 16);
 #ifndef MTN_EMU
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
 #endif
@@ -260,32 +280,28 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     return mtn_check_launch("pose_fwd");
 }
 
-template <class T, int CC>
-static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, void* dtok, float* slab, int B, int h, int w, int J,
-                           hipStream_t stream) {
-    const size_t lds = ((size_t)2 * h * w * CC + (size_t)(256 / CC) * J * CC) * sizeof(float);
-    MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS", h, w);
-#ifndef MTN_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
-    MTN_LAUNCH((pose_bwd_kernel<T, CC>), dim3(DIM / CC, B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
-    return mtn_check_launch("pose_bwd");
-}
-
-int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW, float* dbias, float* slab,
+int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                      int dtype, int B, int h, int w, int J, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
-    int rc;
-    const bool small = (size_t)h * w <= 256;
-    if (dtype == MTN_BF16) rc = small ? pose_bwd_launch<bf16_t, 64>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
-                                      : pose_bwd_launch<bf16_t, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
-    else rc = small ? pose_bwd_launch<float, 64>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
-                    : pose_bwd_launch<float, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    size_t tail = (size_t)J * PXC;
+    if ((size_t)PL * J * CC > tail) tail = (size_t)PL * J * CC;
+    const size_t lds = ((size_t)2 * h * w * CC + tail) * sizeof(float);
+    MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS", h, w);
+#ifndef MTN_EMU
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+#endif
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(pose_bwd_kernel<bf16_t>, dim3(DIM / CC, B), dim3(256), lds, stream, (const bf16_t*)tok, W, dhm, (bf16_t*)dtok, slab, h, w, J);
+    else
+        MTN_LAUNCH(pose_bwd_kernel<float>, dim3(DIM / CC, B), dim3(256), lds, stream, (const float*)tok, W, dhm, (float*)dtok, slab, h, w, J);
+    int rc = mtn_check_launch("pose_bwd");
     if (rc) return rc;
-    MTN_LAUNCH(pose_bias_grad_kernel, dim3(J), dim3(256), 0, stream, dhm, dbias, B, J, 16 * h * w);
-    rc = mtn_check_launch("pose_bias_grad");
-    if (rc) return rc;
-    return mtn_colsum_run(slab, B, J * DIM, dW, stream);
+    return mtn_colsum_run(slab, B, J * (DIM + 1), dW_dbias, stream);
 }
 
 int mtn_loss_blocks(long n) {

@@ -70,28 +70,67 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wp);
 
     // ---- per-thread loader state: RA rows of A (pixel decode), RB rows of W -------------------
+    // Row order: natural (b, oy, ox), or -- for stride-2 data gradients (p.pm) -- parity-major
+    // (oy&1, ox&1, b, oy/2, ox/2): a tile then holds pixels of ONE parity class, for which only
+    // 1, 2 or 4 of the 9 taps can hit a stored gradient, and the K loop skips the others
+    // (2.25 taps on average instead of 9).  Output rows are always written at the natural index.
+    auto decode = [&](int m, int& b, int& oy, int& ox) {
+        if (p.pm) {
+            const int h2 = p.OH >> 1, w2 = p.OW >> 1, per = p.B * h2 * w2;
+            const int q = m / per, r = m - q * per;
+            b = r / (h2 * w2);
+            const int rr = r - b * h2 * w2, y2 = rr / w2;
+            oy = 2 * y2 + (q >> 1);
+            ox = 2 * (rr - y2 * w2) + (q & 1);
+        } else {
+            const int ohw = p.OH * p.OW;
+            b = m / ohw;
+            const int rem = m - b * ohw;
+            oy = rem / p.OW;
+            ox = rem - oy * p.OW;
+        }
+    };
     const int chunk = tid & 7;
     const int row0 = tid >> 3;
+    const int dshift = p.div >> 1, dmask = p.div - 1;     // div in {1,2}
     int a_y[RA], a_x[RA], a_base[RA];
+    unsigned my_taps = 0;
     MTN_UNROLL for (int i = 0; i < RA; ++i) {
         const int m = m0 + row0 + i * RSTEP;
         if (m < p.M) {
-            const int ohw = p.OH * p.OW;
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            int b, oy, ox;
+            decode(m, b, oy, ox);
             a_y[i] = oy * p.mul + p.off;
             a_x[i] = ox * p.mul + p.off;
             a_base[i] = b * p.H * p.W;
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int ty = a_y[i] + (t / p.KW) * p.sgn, tx = a_x[i] + (t % p.KW) * p.sgn;
+                if (ty >= 0 && tx >= 0 && (ty & dmask) == 0 && (tx & dmask) == 0 && (ty >> dshift) < p.H && (tx >> dshift) < p.W)
+                    my_taps |= 1u << t;
+            }
         } else {
             a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0;
         }
     }
-    const int dshift = p.div >> 1, dmask = p.div - 1;     // div in {1,2}
+    // taps that touch at least one row of this tile (workgroup-wide OR through LDS)
+    int* s_taps = reinterpret_cast<int*>(smem);
+    if (tid == 0) *s_taps = 0;
+    __syncthreads();
+    if (my_taps) atomicOr(s_taps, (int)my_taps);
+    __syncthreads();
+    const unsigned tile_taps = (unsigned)*s_taps;
+    __syncthreads();
+    unsigned long long tap_list = 0;                       // 4 bits per listed tap (no indexed array)
+    int ntaps = 0;
+    for (int t = 0; t < 9; ++t)
+        if (tile_taps & (1u << t)) { tap_list |= (unsigned long long)t << (4 * ntaps); ++ntaps; }
+    const int spt = p.Cin / BK;                            // K steps per tap
 
     chunk16 ra[RA], rb[RB];
     auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
-        const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+        const int ti = kt / spt, c0 = (kt - ti * spt) * BK;
+        const int tap = (int)((tap_list >> (4 * ti)) & 15ull);
+        const int k0 = tap * p.Cin + c0;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         MTN_UNROLL for (int i = 0; i < RA; ++i) {
             const int ty = a_y[i] + kh * p.sgn, tx = a_x[i] + kw * p.sgn;
@@ -123,12 +162,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
 
-    const int KT = p.K / BK;
+    const int KT = ntaps * spt;
     const int frow = lane & 15;
     const int fk = (lane >> 4) * (KI / 4);
 
-    load_tiles(0);
-    store_tiles(0);
+    if (KT > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
@@ -159,8 +200,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int CPR = BN / VEC;     // chunks per row
     for (int idx = tid; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR, col = (idx - row * CPR) * VEC;
-        const int m = m0 + row;
+        int m = m0 + row;
         if (m >= p.M) continue;
+        if (p.pm) {
+            int b, oy, ox;
+            decode(m, b, oy, ox);
+            m = (b * p.OH + oy) * p.OW + ox;
+        }
         float v[VEC];
         MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = sC[row * CP + col + e];
         if (p.bias) {
@@ -248,6 +294,8 @@ int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.Cin % bk == 0, "igemm: Cin=%d must be a multiple of %d", p.Cin, bk);
     MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "igemm: K=%d != KH*KW*Cin", p.K);
     MTN_REQUIRE(p.div == 1 || p.div == 2, "igemm: div=%d", p.div);
+    MTN_REQUIRE(p.KH * p.KW <= 9, "igemm: at most 9 taps");
+    MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && !p.stats), "igemm: parity-major rows need even OH/OW");
     MTN_REQUIRE(p.lda % (bk / 8) == 0 && p.ldc % (bk / 8) == 0, "igemm: lda/ldc must keep 16-byte alignment");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "igemm: M=%d != B*OH*OW", p.M);
     MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 31) && (long)p.M * p.ldc < (1L << 31), "igemm: tensor too large for 32-bit offsets");

@@ -23,6 +23,7 @@ struct IgemmArgs {
     const void* res;      // residual [M][ldr] added after act, or null (may alias Out)
     int ldr;
     float* stats;         // [tiles_m][2][N] BN partial sums, or null
+    int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
 };
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
@@ -102,7 +103,7 @@ int mtn_cls_head_bwd_run(const float* dlogits, const float* W, const float* lg, 
                          float* partial, int dtype, int B, int C, hipStream_t stream);
 int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
                      hipStream_t stream);
-int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW, float* dbias, float* slab,
+int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                      int dtype, int B, int h, int w, int J, hipStream_t stream);
 int mtn_loss_blocks(long n);
 int mtn_loss_run(const float* logits, const long long* label, const float* hm, const float* tgt, const float* tw, float* dlogits,

@@ -42,7 +42,15 @@ template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return f
 template <class T> __device__ __forceinline__ float round_to(float x) { return to_f<T>(from_f<T>(x)); }
 
 // 16-byte chunk: the unit of every global<->LDS move (8 bf16 or 4 f32)
-struct alignas(16) chunk16 { unsigned w[4]; };
+#ifdef MTN_EMU
+struct alignas(16) chunk16 {
+    unsigned w[4];
+    unsigned& operator[](int i) { return w[i]; }
+    const unsigned& operator[](int i) const { return w[i]; }
+};
+#else
+typedef unsigned chunk16 __attribute__((ext_vector_type(4)));     // one VGPR quad, never an array in scratch
+#endif
 template <class T> struct Vec { static constexpr int N = 16 / sizeof(T); };
 
 template <class T> __device__ __forceinline__ void unpack(const chunk16& c, float* f);
@@ -50,12 +58,12 @@ template <> __device__ __forceinline__ void unpack<float>(const chunk16& c, floa
 #ifdef MTN_EMU
     std::memcpy(f, c.w, 16);
 #else
-    MTN_UNROLL for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c.w[i]);
+    MTN_UNROLL for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c[i]);
 #endif
 }
 template <> __device__ __forceinline__ void unpack<bf16_t>(const chunk16& c, float* f) {
     MTN_UNROLL for (int i = 0; i < 4; ++i) {
-        bf16_t lo, hi; lo.v = (unsigned short)(c.w[i] & 0xffffu); hi.v = (unsigned short)(c.w[i] >> 16);
+        bf16_t lo, hi; lo.v = (unsigned short)(c[i] & 0xffffu); hi.v = (unsigned short)(c[i] >> 16);
         f[2 * i] = bf2f(lo); f[2 * i + 1] = bf2f(hi);
     }
 }
@@ -65,17 +73,17 @@ template <> __device__ __forceinline__ chunk16 pack<float>(const float* f) {
 #ifdef MTN_EMU
     std::memcpy(c.w, f, 16);
 #else
-    MTN_UNROLL for (int i = 0; i < 4; ++i) c.w[i] = __float_as_uint(f[i]);
+    MTN_UNROLL for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
 #endif
     return c;
 }
 template <> __device__ __forceinline__ chunk16 pack<bf16_t>(const float* f) {
     chunk16 c;
     MTN_UNROLL for (int i = 0; i < 4; ++i)
-        c.w[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
+        c[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
     return c;
 }
-__device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0u; return c; }
+__device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c[0] = 0u; c[1] = 0u; c[2] = 0u; c[3] = 0u; return c; }
 
 // ---- MFMA, 16x16 output tile -------------------------------------------------------------
 // Mma<T>::KI = K depth of one instruction; Frag = one lane's A or B operand.

@@ -172,16 +172,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
             }
 }
 
-// dW_oihw[o][ci][kh][kw] = sum_s partial[s][o][(kh*KW+kw)*Cin + ci]
+// dW_oihw[o][ci][kh][kw] = sum_s partial[s][o][(kh*KW+kw)*Cin + ci]; block = 4 split lanes x 64 elements
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int splits, int N, int K, int Cin, int taps) {
+    __shared__ float red[4][64];
+    const int sl = threadIdx.x >> 6, el = threadIdx.x & 63;
     const long total = (long)N * K;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int q = 0; q < splits; ++q) s += partial[(long)q * total + idx];
+    const long idx = (long)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (idx < total)
+        for (int q = sl; q < splits; q += 4) s += partial[(long)q * total + idx];
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && idx < total) {
         const int n = (int)(idx / K), k = (int)(idx - (long)n * K);
         const int tap = k / Cin, ci = k - tap * Cin;
-        dw[((long)n * Cin + ci) * taps + tap] = s;
+        dw[((long)n * Cin + ci) * taps + tap] = red[0][el] + red[1][el] + red[2][el] + red[3][el];
     }
 }
 
@@ -216,7 +222,7 @@ int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_spli
     const int t = big_tile(N, Cin) ? 128 : 64;
     const long tiles = (long)(N / t) * (K / t);
     long want = (M + 4095) / 4096;
-    const long fill = (1024 + tiles - 1) / tiles;
+    const long fill = (512 + tiles - 1) / tiles;
     if (want < fill) want = fill;
     long rps = (M + want - 1) / want;
     rps = (rps + bmr - 1) / bmr * bmr;
@@ -247,7 +253,7 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     }
     if (rc) return rc;
     const long total = (long)p.N * p.K;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const int blocks = (int)((total + 63) / 64);
     MTN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p.partial, p.dW, p.splits, p.N, p.K,
                p.Cin, p.KH * p.KW);
     return mtn_check_launch("wgrad_reduce");

@@ -190,7 +190,7 @@ class Engine:
         self.hm = self._f32(B, self.J, 4 * self.fh, 4 * self.fw)
         self.cls_xhat, self.cls_mr = self._f32(B, D), self._f32(B, 2)
         self.cls_part = self._f32(ops.slab_rows(B), 2 * D)
-        self.pose_slab = self._f32(ops.slab_rows(B), self.J * D)
+        self.pose_slab = self._f32(ops.slab_rows(B), self.J * (D + 1))
         self.dlogits, self.dhm = self._f32(B, self.C), torch.empty_like(self.hm)
         self.loss_part = self._f32(ops.loss_partial_len(self.hm.numel()))
         self.losses = self._f32(3)
@@ -333,7 +333,7 @@ class Engine:
         xl = self.x[-1]
         ops.cls_head_bwd(dlogits, head[1].weight, head[0].weight, head[0].bias, self.cls_xhat, self.cls_mr, G,
                          g(head[1].weight), g(head[1].bias), self._pair(head[0].weight, head[0].bias), self.cls_part)
-        ops.pose_head_bwd(xl, pw.weight, dhm, G, g(pw.weight), g(pw.bias), self.pose_slab, self.fh, self.fw)
+        ops.pose_head_bwd(xl, pw.weight, dhm, G, self._pair(pw.weight, pw.bias), self.pose_slab, self.fh, self.fw)
         for i in reversed(range(len(self.layers))):
             L = self.layers[i]
             x0, x1 = self.x[2 * i].view(Mt, D), self.x[2 * i + 1].view(Mt, D)
@@ -365,7 +365,8 @@ class Engine:
         self.backbone_backward(last["g_out"])
 
     def _pair(self, w, b):
-        """[2][256] gradient slot of a LayerNorm (weight grad then bias grad, adjacent in the flat buffer)."""
+        """Gradient slot of a (weight, bias) pair that one kernel writes as one block: the two are
+        adjacent in the flat gradient buffer because they are consecutive in parameters() order."""
         gw, gb = self._g(w), self._g(b)
-        assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4, "LayerNorm weight/bias grads must be adjacent"
+        assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4, "weight/bias grads must be adjacent"
         return gw

@@ -47,7 +47,7 @@ _PROTOS = {
     "mtn_cls_head_fwd": [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "mtn_cls_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_pose_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "mtn_pose_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_pose_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_loss_partial_len": [_ll],
     "mtn_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mtn_adamw_step": [_vp, _vp, _vp, _vp, _ll, _vp, _vp],

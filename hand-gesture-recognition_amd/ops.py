@@ -250,10 +250,11 @@ def pose_head_fwd(tok, W, bias, hm, h, w):
              dtype_code(tok), B, h, w, J, _stream(tok))
 
 
-def pose_head_bwd(tok, W, dhm, dtok, dW, dbias, slab, h, w):
+def pose_head_bwd(tok, W, dhm, dtok, dW_dbias, slab, h, w):
+    """dW_dbias: f32 [J*256 + J] = weight gradient followed by the bias gradient."""
     B, J = dhm.shape[:2]
     lib.call("mtn_pose_head_bwd", tok.data_ptr(), W.data_ptr(), dhm.data_ptr(), dtok.data_ptr(),
-             dW.data_ptr(), dbias.data_ptr(), slab.data_ptr(), dtype_code(tok), B, h, w, J, _stream(tok))
+             dW_dbias.data_ptr(), slab.data_ptr(), dtype_code(tok), B, h, w, J, _stream(tok))
 
 
 def loss_partial_len(n):

@@ -159,9 +159,10 @@ int mtn_cls_head_bwd(const float* dlogits, const float* W, const float* ln_w, co
  * tok [B][h*w+1][256] (row 0 = cls, skipped); hm f32 NCHW [B][J][4h][4w]. */
 int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B,
                       int h, int w, int J, void* stream);
-/* writes dtok rows 1.., dW [J][256], dbias [J]; slab f32 [mtn_slab_rows(B)][J*256] */
-int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW,
-                      float* dbias, float* slab, int dtype, int B, int h, int w, int J, void* stream);
+/* writes dtok rows 1.. and dW_dbias = [dW [J][256] | dbias [J]] (one contiguous f32 block);
+ * slab f32 [mtn_slab_rows(B)][J*257] */
+int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias,
+                      float* slab, int dtype, int B, int h, int w, int J, void* stream);
 
 /* ---- loss + its gradients (libs/loss.py:4-40, train.py:63-64,75) --------------------------------
  * losses[3] = (total, ce_weight*CE, JointsMSE); dlogits [B][C], dhm like hm (either may be NULL);
