@@ -102,21 +102,33 @@ __global__ __launch_bounds__(256) void pose_fwd_kernel(const T* __restrict__ tok
     }
 }
 
-// Backward.  block = (channel chunk of CC, image b); threads = CC channels x PL pixel lanes.  The
-// image's heat-map gradient is streamed through LDS in chunks of PXC pixels (coalesced loads); each
-// thread recomputes u for its channel, forms g = sum_j d[j]*W[j][c], accumulates dW[j][c] in
-// registers and scatters g through the transposed bilinear stencil into an LDS token-gradient tile
-// (ds_add_f32: lanes of a wave hit consecutive banks).  slab row b = [dW (J*256) | dbias (J)].
-constexpr int CC = 32, PL = 256 / CC, PXC = 256;
-template <class T>
+// Backward.  block = (channel chunk of CC, image b), 256 threads = CC channels x PL lanes.
+// The heat-map gradient of the image streams through LDS RB output rows at a time.
+//   phase 1 (thread = channel x group of 4 consecutive pixels): recompute u, g = sum_j d_j W_jc with
+//            one ds_read_b128 of d per joint per 4 pixels, dW[j][c] += d_j * relu(u) in registers,
+//            du = g * [u > 0] -> LDS;
+//   phase 2 (thread = channel x OWNED source column): gather the transposed bilinear stencil from
+//            du: every token-gradient cell has exactly one writer, so there are no atomics and the
+//            result is deterministic.
+// Interpolation coordinates come from per-block LDS tables (PyTorch's align_corners=True map).
+// slab row b = [dW (J*256) | dbias (J)].
+constexpr int RB = 4;
+template <class T, int CC>
 __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                        const float* __restrict__ dhm, T* __restrict__ dtok,
                                                        float* __restrict__ slab, int h, int w, int J) {
+    constexpr int PL = 256 / CC;
     MTN_DYN_SMEM(smem);
-    const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW;
+    const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW, RP = RB * OW;
     float* sS = reinterpret_cast<float*>(smem);         // source tokens [hw][CC]
-    float* sG = sS + hw * CC;                           // token-gradient accumulator [hw][CC]
-    float* sD = sG + hw * CC;                           // [J][PXC] chunk of dhm; later [PL][J][CC] / [4][J]
+    float* sG = sS + hw * CC;                           // token gradient [hw][CC]
+    float* sD = sG + hw * CC;                           // [J][RP] rows of dhm; at the end [PL][J][CC]
+    float* sU = sD + ((J * RP > PL * J * CC) ? J * RP : PL * J * CC);   // du [RP][CC]
+    int* tI0 = reinterpret_cast<int*>(sU + RP * CC);    // [OH + OW] lerp tables
+    int* tI1 = tI0 + OH + OW;
+    float* tW = reinterpret_cast<float*>(tI1 + OH + OW);
+    int* tLo = reinterpret_cast<int*>(tW + OH + OW);    // [w] first / last output column touching a source column
+    int* tHi = tLo + w;
     const int b = blockIdx.y, c0 = blockIdx.x * CC;
     const int c = threadIdx.x % CC, pl = threadIdx.x / CC;
     const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + c0;
@@ -125,43 +137,76 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
         sS[i] = to_f<T>(base[(long)p * DIM + cc]);
         sG[i] = 0.f;
     }
+    for (int i = threadIdx.x; i < OH + OW; i += 256) {
+        const Lerp l = i < OH ? lerp_coord(i, h, OH) : lerp_coord(i - OH, w, OW);
+        tI0[i] = l.i0; tI1[i] = l.i1; tW[i] = l.w1;
+    }
+    __syncthreads();
+    for (int sx = threadIdx.x; sx < w; sx += 256) {
+        int lo = OW, hi = -1;
+        for (int ox = 0; ox < OW; ++ox)
+            if (tI0[OH + ox] == sx || tI1[OH + ox] == sx) { if (ox < lo) lo = ox; hi = ox; }
+        tLo[sx] = lo; tHi[sx] = hi;
+    }
     float wj[MAXJ], dw[MAXJ], db[MAXJ];
     MTN_UNROLL for (int j = 0; j < MAXJ; ++j) { wj[j] = j < J ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; db[j] = 0.f; }
     const float* dh = dhm + (long)b * J * OHW;
     const bool do_bias = blockIdx.x == 0;
-    for (int pb = 0; pb < OHW; pb += PXC) {
+    for (int r0 = 0; r0 < OH; r0 += RB) {
         __syncthreads();
-        for (int i = threadIdx.x; i < J * PXC; i += 256) {
-            const int j = i / PXC, p = i - j * PXC;
-            sD[i] = (pb + p < OHW) ? dh[(long)j * OHW + pb + p] : 0.f;
+        for (int i = threadIdx.x; i < J * RP; i += 256) {
+            const int j = i / RP, p = i - j * RP;
+            sD[i] = (r0 * OW + p < OHW) ? dh[(long)j * OHW + r0 * OW + p] : 0.f;
         }
         __syncthreads();
         if (do_bias) {
-            MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
-                if (j < J) db[j] += sD[j * PXC + threadIdx.x];
+            for (int p = threadIdx.x; p < RP; p += 256)
+                MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
+                    if (j < J) db[j] += sD[j * RP + p];
         }
-        for (int pp = pl; pp < PXC && pb + pp < OHW; pp += PL) {
-            const int px = pb + pp;
-            const int oy = px / OW, ox = px - oy * OW;
-            const Lerp ly = lerp_coord(oy, h, OH), lx = lerp_coord(ox, w, OW);
-            const float wy0 = 1.f - ly.w1, wx0 = 1.f - lx.w1;
-            const int i00 = (ly.i0 * w + lx.i0) * CC + c, i01 = (ly.i0 * w + lx.i1) * CC + c;
-            const int i10 = (ly.i1 * w + lx.i0) * CC + c, i11 = (ly.i1 * w + lx.i1) * CC + c;
-            const float v = wy0 * (wx0 * sS[i00] + lx.w1 * sS[i01]) + ly.w1 * (wx0 * sS[i10] + lx.w1 * sS[i11]);
-            const float u = v > 0.f ? v : 0.f;
-            float gsum = 0.f;
-            MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
-                if (j < J) {
-                    const float d = sD[j * PXC + pp];
-                    gsum += d * wj[j];
-                    dw[j] += d * u;
+        // phase 1
+        for (int gq = pl; gq < RP / 4; gq += PL) {
+            const int p0 = gq * 4, r = p0 / OW, ox0 = p0 - r * OW, oy = r0 + r;
+            float u[4], gs[4];
+            if (oy < OH) {
+                const int y0 = tI0[oy] * w, y1 = tI1[oy] * w;
+                const float wy = tW[oy];
+                MTN_UNROLL for (int e = 0; e < 4; ++e) {
+                    const int x0 = tI0[OH + ox0 + e], x1 = tI1[OH + ox0 + e];
+                    const float wx = tW[OH + ox0 + e];
+                    u[e] = (1.f - wy) * ((1.f - wx) * sS[(y0 + x0) * CC + c] + wx * sS[(y0 + x1) * CC + c]) +
+                           wy * ((1.f - wx) * sS[(y1 + x0) * CC + c] + wx * sS[(y1 + x1) * CC + c]);
+                    gs[e] = 0.f;
                 }
+                MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
+                    if (j < J) {
+                        const float4 d = *reinterpret_cast<const float4*>(sD + j * RP + p0);
+                        const float ww = wj[j];
+                        gs[0] += d.x * ww; gs[1] += d.y * ww; gs[2] += d.z * ww; gs[3] += d.w * ww;
+                        dw[j] += d.x * fmaxf(u[0], 0.f) + d.y * fmaxf(u[1], 0.f) + d.z * fmaxf(u[2], 0.f) + d.w * fmaxf(u[3], 0.f);
+                    }
+                }
+                MTN_UNROLL for (int e = 0; e < 4; ++e) sU[(p0 + e) * CC + c] = u[e] > 0.f ? gs[e] : 0.f;
+            } else {
+                MTN_UNROLL for (int e = 0; e < 4; ++e) sU[(p0 + e) * CC + c] = 0.f;
             }
-            if (v > 0.f) {
-                atomicAdd(&sG[i00], gsum * wy0 * wx0);
-                atomicAdd(&sG[i01], gsum * wy0 * lx.w1);
-                atomicAdd(&sG[i10], gsum * ly.w1 * wx0);
-                atomicAdd(&sG[i11], gsum * ly.w1 * lx.w1);
+        }
+        __syncthreads();
+        // phase 2: thread (c, owner pl) owns source columns pl, pl+PL, ...
+        for (int sx = pl; sx < w; sx += PL) {
+            const int lo = tLo[sx], hi = tHi[sx];
+            for (int r = 0; r < RB && r0 + r < OH; ++r) {
+                float sum = 0.f;
+                for (int ox = lo; ox <= hi; ++ox) {
+                    const int x0 = tI0[OH + ox], x1 = tI1[OH + ox];
+                    const float wx = tW[OH + ox];
+                    const float wgt = (x0 == sx ? 1.f - wx : 0.f) + ((x1 == sx && x1 != x0) ? wx : 0.f);
+                    sum += wgt * sU[(r * OW + ox) * CC + c];
+                }
+                const int oy = r0 + r;
+                const float wy = tW[oy];
+                sG[(tI0[oy] * w + sx) * CC + c] += (1.f - wy) * sum;
+                if (tI1[oy] != tI0[oy]) sG[(tI1[oy] * w + sx) * CC + c] += wy * sum;
             }
         }
     }
@@ -268,8 +313,6 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
 #endif
@@ -280,26 +323,31 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     return mtn_check_launch("pose_fwd");
 }
 
+template <class T, int CC>
+static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, void* dtok, float* slab, int B, int h, int w,
+                           int J, hipStream_t stream) {
+    const int OH = 4 * h, OW = 4 * w, RP = RB * OW, PL = 256 / CC;
+    const size_t tail = (size_t)(J * RP > PL * J * CC ? J * RP : PL * J * CC);
+    const size_t lds = ((size_t)2 * h * w * CC + tail + (size_t)RP * CC + 3 * (size_t)(OH + OW) + 2 * (size_t)w) * 4;
+    MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS (%zu bytes)", h, w, lds);
+#ifndef MTN_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    MTN_LAUNCH((pose_bwd_kernel<T, CC>), dim3(DIM / CC, B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
+    return mtn_check_launch("pose_bwd");
+}
+
+void mtn_pose_set_dbg(int) {}
+
 int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                      int dtype, int B, int h, int w, int J, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
-    size_t tail = (size_t)J * PXC;
-    if ((size_t)PL * J * CC > tail) tail = (size_t)PL * J * CC;
-    const size_t lds = ((size_t)2 * h * w * CC + tail) * sizeof(float);
-    MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS", h, w);
-#ifndef MTN_EMU
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
-#endif
-    if (dtype == MTN_BF16)
-        MTN_LAUNCH(pose_bwd_kernel<bf16_t>, dim3(DIM / CC, B), dim3(256), lds, stream, (const bf16_t*)tok, W, dhm, (bf16_t*)dtok, slab, h, w, J);
-    else
-        MTN_LAUNCH(pose_bwd_kernel<float>, dim3(DIM / CC, B), dim3(256), lds, stream, (const float*)tok, W, dhm, (float*)dtok, slab, h, w, J);
-    int rc = mtn_check_launch("pose_bwd");
+    const bool small = h * w <= 256;
+    int rc;
+    if (dtype == MTN_BF16) rc = small ? pose_bwd_launch<bf16_t, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
+                                      : pose_bwd_launch<bf16_t, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    else rc = small ? pose_bwd_launch<float, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
+                    : pose_bwd_launch<float, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
     if (rc) return rc;
     return mtn_colsum_run(slab, B, J * (DIM + 1), dW_dbias, stream);
 }

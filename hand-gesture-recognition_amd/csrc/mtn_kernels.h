@@ -112,3 +112,4 @@ int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* s
 int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream);
 int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                     float* scale_shift, int C, hipStream_t stream);
+void mtn_pose_set_dbg(int v);

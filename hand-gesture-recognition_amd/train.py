@@ -136,10 +136,15 @@ class TrainStep:
         return self.eng.losses
 
     def _capture(self, img, label, target, tw):
+        """Warm up once eagerly (lazy kernel attributes, allocator), capture, then restore every piece
+        of training state the warm-up step touched so that capture is invisible to the trajectory."""
         self._static = [t.clone() for t in (img, label, target, tw)]
+        mdl = self.model
+        keep = [mdl.flat_params, self.m, self.v, self.state] + list(mdl.buffers())
+        saved = [t.clone() for t in keep]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):            # warm-up outside capture (lazy kernel attributes etc.)
+        with torch.cuda.stream(s):
             self._eager(*self._static)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -156,6 +161,10 @@ class TrainStep:
             with torch.cuda.graph(g2):
                 self._update()
             self._graph = (g1, g2)
+        with torch.no_grad():
+            for t, sv in zip(keep, saved):
+                t.copy_(sv)
+        torch.cuda.synchronize()
 
     def __call__(self, img, label, target, target_weight):
         if not (self.use_graph and img.is_cuda):
