@@ -122,9 +122,10 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
     const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW, RP = RB * OW;
     float* sS = reinterpret_cast<float*>(smem);         // source tokens [hw][CC]
     float* sG = sS + hw * CC;                           // token gradient [hw][CC]
-    float* sD = sG + hw * CC;                           // [J][RP] rows of dhm; at the end [PL][J][CC]
-    float* sU = sD + ((J * RP > PL * J * CC) ? J * RP : PL * J * CC);   // du [RP][CC]
-    int* tI0 = reinterpret_cast<int*>(sU + RP * CC);    // [OH + OW] lerp tables
+    float* sD = sG + hw * CC;                           // [J][RP] rows of dhm
+    float* sU = sD + J * RP;                            // du [RP][CC]; sD|sU are reused as [PL][J][CC] at the end
+    const int tail = (J * RP + RP * CC > PL * J * CC) ? J * RP + RP * CC : PL * J * CC;
+    int* tI0 = reinterpret_cast<int*>(sD + tail);       // [OH + OW] lerp tables
     int* tI1 = tI0 + OH + OW;
     float* tW = reinterpret_cast<float*>(tI1 + OH + OW);
     int* tLo = reinterpret_cast<int*>(tW + OH + OW);    // [w] first / last output column touching a source column
@@ -327,8 +328,8 @@ template <class T, int CC>
 static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, void* dtok, float* slab, int B, int h, int w,
                            int J, hipStream_t stream) {
     const int OH = 4 * h, OW = 4 * w, RP = RB * OW, PL = 256 / CC;
-    const size_t tail = (size_t)(J * RP > PL * J * CC ? J * RP : PL * J * CC);
-    const size_t lds = ((size_t)2 * h * w * CC + tail + (size_t)RP * CC + 3 * (size_t)(OH + OW) + 2 * (size_t)w) * 4;
+    const size_t tail = (size_t)(J * RP + RP * CC > PL * J * CC ? J * RP + RP * CC : PL * J * CC);
+    const size_t lds = ((size_t)2 * h * w * CC + tail + 3 * (size_t)(OH + OW) + 2 * (size_t)w) * 4;
     MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS (%zu bytes)", h, w, lds);
 #ifndef MTN_EMU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -342,12 +343,9 @@ void mtn_pose_set_dbg(int) {}
 int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                      int dtype, int B, int h, int w, int J, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
-    const bool small = h * w <= 256;
-    int rc;
-    if (dtype == MTN_BF16) rc = small ? pose_bwd_launch<bf16_t, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
-                                      : pose_bwd_launch<bf16_t, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
-    else rc = small ? pose_bwd_launch<float, 32>(tok, W, dhm, dtok, slab, B, h, w, J, stream)
-                    : pose_bwd_launch<float, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    int rc;       // 16-channel chunks: ~48 KB of LDS at 12x12 tokens -> 3 workgroups per CU hide the LDS latency
+    if (dtype == MTN_BF16) rc = pose_bwd_launch<bf16_t, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    else rc = pose_bwd_launch<float, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
     if (rc) return rc;
     return mtn_colsum_run(slab, B, J * (DIM + 1), dW_dbias, stream);
 }

@@ -21,6 +21,7 @@
 // BN statistics (model/gelan.py:46, train mode): every tile writes its per-channel sum and
 // sum-of-squares over the tile's rows to stats[tile_m][2][N]; bn_finalize reduces the slab in
 // tile order -> deterministic, no float atomics.
+#include <type_traits>
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
@@ -29,7 +30,10 @@ namespace {
 constexpr int ROW_BYTES = 128;          // reduction bytes per row per K step
 constexpr int PITCH_BYTES = 144;        // padded LDS row
 
-template <class T, int BM, int BN, int WGM, int WGN>
+// STAGES = 2: double-buffered LDS, one barrier per K step, f32 C staging (2 workgroups / CU).
+// STAGES = 1: single LDS buffer + register prefetch, two barriers per K step, C staged in T:
+//             half the LDS -> 4 workgroups / CU, whose main loops / epilogues overlap each other.
+template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int BK = ROW_BYTES / (int)sizeof(T);
@@ -41,14 +45,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int RA = BM * 8 / NT;      // A chunks per thread per K step
     constexpr int RB = BN * 8 / NT;      // W chunks per thread per K step
     constexpr int RSTEP = NT / 8;        // rows between a thread's chunks
-    constexpr int CP = BN + 4;           // f32 pitch of the staged C tile
+    typedef typename std::conditional<STAGES == 1, T, float>::type CT;     // staged C element
+    constexpr int CP = BN + 16 / (int)sizeof(CT);                          // pitch of the staged C tile
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "loader mapping");
-    static_assert(NT % BN == 0, "stats mapping");
 
     MTN_DYN_SMEM(smem);
-    T* const sA = reinterpret_cast<T*>(smem);                       // [2][BM][PITCH]
-    T* const sB = sA + 2 * BM * PITCH;                              // [2][BN][PITCH]
-    float* const sC = reinterpret_cast<float*>(smem);               // [BM][CP] (after the K loop)
+    T* const sA = reinterpret_cast<T*>(smem);                       // [STAGES][BM][PITCH]
+    T* const sB = sA + STAGES * BM * PITCH;                         // [STAGES][BN][PITCH]
+    CT* const sC = reinterpret_cast<CT*>(smem);                     // [BM][CP] (after the K loop)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             a_y[i] = oy * p.mul + p.off;
             a_x[i] = ox * p.mul + p.off;
             a_base[i] = b * p.H * p.W;
+            if (p.pm)
             for (int t = 0; t < p.KH * p.KW; ++t) {
                 const int ty = a_y[i] + (t / p.KW) * p.sgn, tx = a_x[i] + (t % p.KW) * p.sgn;
                 if (ty >= 0 && tx >= 0 && (ty & dmask) == 0 && (tx & dmask) == 0 && (ty >> dshift) < p.H && (tx >> dshift) < p.W)
@@ -112,14 +117,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0;
         }
     }
-    // taps that touch at least one row of this tile (workgroup-wide OR through LDS)
-    int* s_taps = reinterpret_cast<int*>(smem);
-    if (tid == 0) *s_taps = 0;
-    __syncthreads();
-    if (my_taps) atomicOr(s_taps, (int)my_taps);
-    __syncthreads();
-    const unsigned tile_taps = (unsigned)*s_taps;
-    __syncthreads();
+    // taps that touch at least one row of this tile (workgroup-wide OR through LDS); only the
+    // parity-major data gradient can skip taps, everything else runs all of them
+    unsigned tile_taps = (1u << (p.KH * p.KW)) - 1u;
+    if (p.pm) {
+        int* s_taps = reinterpret_cast<int*>(smem);
+        if (tid == 0) *s_taps = 0;
+        __syncthreads();
+        if (my_taps) atomicOr(s_taps, (int)my_taps);
+        __syncthreads();
+        tile_taps = (unsigned)*s_taps;
+        __syncthreads();
+    }
     unsigned long long tap_list = 0;                       // 4 bits per listed tap (no indexed array)
     int ntaps = 0;
     for (int t = 0; t < 9; ++t)
@@ -166,16 +175,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     const int frow = lane & 15;
     const int fk = (lane >> 4) * (KI / 4);
 
-    if (KT > 0) {
-        load_tiles(0);
-        store_tiles(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_tiles(kt + 1);
-        const T* a = sA + cur * BM * PITCH + (wm * WM + frow) * PITCH + fk;
-        const T* b = sB + cur * BN * PITCH + (wn * WN + frow) * PITCH + fk;
+    auto compute = [&](int stage) {
+        const T* a = sA + stage * BM * PITCH + (wm * WM + frow) * PITCH + fk;
+        const T* b = sB + stage * BN * PITCH + (wn * WN + frow) * PITCH + fk;
         MTN_UNROLL for (int ks = 0; ks < BK / KI; ++ks) {
             typename Mma<T>::Frag fa[FM], fb[FN];
             MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = Mma<T>::load(a + i * 16 * PITCH + ks * KI);
@@ -183,23 +185,48 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             MTN_UNROLL for (int i = 0; i < FM; ++i)
                 MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
         }
-        if (kt + 1 < KT) store_tiles(cur ^ 1);
+    };
+    if (STAGES == 2) {
+        if (KT > 0) {
+            load_tiles(0);
+            store_tiles(0);
+        }
         __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) load_tiles(kt + 1);
+            compute(cur);
+            if (kt + 1 < KT) store_tiles(cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        if (KT > 0) load_tiles(0);
+        for (int kt = 0; kt < KT; ++kt) {
+            store_tiles(0);
+            __syncthreads();
+            if (kt + 1 < KT) load_tiles(kt + 1);      // in flight while this step computes
+            compute(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS (f32) -> row-wise fused math -> 16-byte stores ----------
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j)
             MTN_UNROLL for (int r = 0; r < 4; ++r)
-                sC[(wm * WM + i * 16 + 4 * (lane >> 4) + r) * CP + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r];
+                sC[(wm * WM + i * 16 + 4 * (lane >> 4) + r) * CP + wn * WN + j * 16 + (lane & 15)] = from_f<CT>(acc[i][j][r]);
     __syncthreads();
 
     T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
     T* __restrict__ gAux = reinterpret_cast<T*>(p.aux_out);
     const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
     constexpr int CPR = BN / VEC;     // chunks per row
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
-        const int row = idx / CPR, col = (idx - row * CPR) * VEC;
+    constexpr int TR = NT / CPR;      // thread rows: a thread keeps ONE column chunk for all its rows
+    static_assert(NT % CPR == 0, "store mapping");
+    const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
+    float st_s[VEC], st_q[VEC];
+    MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+    for (int row = trow; row < BM; row += TR) {
         int m = m0 + row;
         if (m >= p.M) continue;
         if (p.pm) {
@@ -208,78 +235,81 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             m = (b * p.OH + oy) * p.OW + ox;
         }
         float v[VEC];
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = sC[row * CP + col + e];
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = to_f<CT>(sC[row * CP + ccol + e]);
         if (p.bias) {
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += p.bias[n0 + col + e];
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += p.bias[n0 + ccol + e];
         }
         if (p.act == MTN_ACT_GELU) {
-            if (gAux) *reinterpret_cast<chunk16*>(gAux + (long)m * p.ld_aux + n0 + col) = pack<T>(v);
+            if (gAux) *reinterpret_cast<chunk16*>(gAux + (long)m * p.ld_aux + n0 + ccol) = pack<T>(v);
             MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = geluf_(v[e]);
         }
         if (gR) {
             float rr[VEC];
-            unpack<T>(*reinterpret_cast<const chunk16*>(gR + (long)m * p.ldr + n0 + col), rr);
+            unpack<T>(*reinterpret_cast<const chunk16*>(gR + (long)m * p.ldr + n0 + ccol), rr);
             MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += rr[e];
         }
         const chunk16 o = pack<T>(v);
-        *reinterpret_cast<chunk16*>(gO + (long)m * p.ldc + n0 + col) = o;
+        *reinterpret_cast<chunk16*>(gO + (long)m * p.ldc + n0 + ccol) = o;
         if (p.stats) {          // statistics of the values exactly as stored
             float w[VEC];
             unpack<T>(o, w);
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) sC[row * CP + col + e] = w[e];
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += w[e]; st_q[e] += w[e] * w[e]; }
         }
     }
     if (p.stats) {
-        __syncthreads();
-        constexpr int PARTS = NT / BN;
-        const int col = tid % BN, part = tid / BN;
-        float s = 0.f, ss = 0.f;
-        const int rows = (p.M - m0 < BM) ? (p.M - m0) : BM;
-        for (int r = part; r < rows; r += PARTS) {
-            const float x = sC[r * CP + col];
-            s += x; ss += x * x;
+        __syncthreads();                                   // everyone is done reading the C tile
+        float* red = reinterpret_cast<float*>(smem);       // [2][TR][BN]
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+            red[trow * BN + ccol + e] = st_s[e];
+            red[(TR + trow) * BN + ccol + e] = st_q[e];
         }
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [PARTS][2][BN]
-        red[(part * 2 + 0) * BN + col] = s;
-        red[(part * 2 + 1) * BN + col] = ss;
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
+        for (int i = tid; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
             float t = 0.f;
-            MTN_UNROLL for (int q = 0; q < PARTS; ++q) t += red[(q * 2 + which) * BN + c];
+            MTN_UNROLL for (int q = 0; q < TR; ++q) t += red[(which * TR + q) * BN + c];
             p.stats[((long)tile_m * 2 + which) * p.N + n0 + c] = t;
         }
     }
 }
 
-template <class T, int BM, int BN, int WGM, int WGN>
+template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
 int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
-    constexpr size_t lds_ab = 2 * (size_t)(BM + BN) * PITCH_BYTES;
-    constexpr size_t lds_c = (size_t)BM * (BN + 4) * 4;
-    constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
+    constexpr size_t lds_ab = STAGES * (size_t)(BM + BN) * PITCH_BYTES;
+    constexpr size_t csz = STAGES == 1 ? sizeof(T) : 4;
+    constexpr size_t lds_c = (size_t)BM * (BN * csz + 16);
+    constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
+    constexpr size_t lds0 = lds_ab > lds_c ? lds_ab : lds_c;
+    constexpr size_t lds = lds0 > lds_r ? lds0 : lds_r;
 #ifndef MTN_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
 #endif
     const int tiles = mtn_cdiv(p.M, BM) * (p.N / BN);
-    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN>), dim3(tiles), dim3(NT), lds, stream, p);
+    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN, STAGES>), dim3(tiles), dim3(NT), lds, stream, p);
     return mtn_check_launch("igemm");
 }
 
+static int g_igemm_stages = 1;
+
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
-    if (p.N % 128 == 0 && p.M >= 128 * 64) return launch_igemm<T, 128, 128, 2, 2>(p, stream);
-    if (p.N % 128 == 0) return launch_igemm<T, 64, 128, 1, 4>(p, stream);
-    return launch_igemm<T, 128, 64, 4, 1>(p, stream);
+    const bool one = g_igemm_stages == 1;
+    if (p.N % 128 == 0 && p.M >= 128 * 64)
+        return one ? launch_igemm<T, 128, 128, 2, 2, 1>(p, stream) : launch_igemm<T, 128, 128, 2, 2, 2>(p, stream);
+    if (p.N % 128 == 0)
+        return one ? launch_igemm<T, 64, 128, 1, 4, 1>(p, stream) : launch_igemm<T, 64, 128, 1, 4, 2>(p, stream);
+    return one ? launch_igemm<T, 128, 64, 4, 1, 1>(p, stream) : launch_igemm<T, 128, 64, 4, 1, 2>(p, stream);
 }
 
 }  // namespace
+
+void mtn_igemm_set_stages(int n) { g_igemm_stages = n == 2 ? 2 : 1; }
 
 int mtn_igemm_tiles_m(int M, int N) {
     if (N % 128 == 0 && M >= 128 * 64) return mtn_cdiv(M, 128);

@@ -113,3 +113,4 @@ int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int
 int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                     float* scale_shift, int C, hipStream_t stream);
 void mtn_pose_set_dbg(int v);
+void mtn_igemm_set_stages(int n);

@@ -181,7 +181,8 @@ int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors, int max_elems,
                      int dtype, void* stream);
 
-/* test hook: key 1 = use ds_read_b64_tr_b16 operand reads in wgrad (default 1) */
+/* test / tuning hook: key 1 = ds_read_b64_tr_b16 operand reads in wgrad (default 1);
+ * key 3 = igemm LDS stages (1: single buffer, 4 workgroups/CU (default); 2: double buffer) */
 int mtn_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -20,6 +20,15 @@ def pack_crsk(w_oihw, dtype):       # dgrad operand [I,kh,kw,O]
     return w_oihw.permute(1, 2, 3, 0).contiguous().to(dtype)
 
 
+@pytest.fixture(params=[1, 2], ids=["lds1", "lds2"])
+def stages(request, be):
+    """both igemm pipelines: single LDS buffer (default) and double buffer"""
+    from hand_gesture_recognition_amd import lib
+    lib.call("mtn_debug_set", 3, request.param)
+    yield request.param
+    lib.call("mtn_debug_set", 3, 1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [
     # B, H, W, Cin, Cout, k, s
@@ -28,7 +37,7 @@ def pack_crsk(w_oihw, dtype):       # dgrad operand [I,kh,kw,O]
     (3, 5, 7, 128, 64, 1, 1),
     (1, 12, 12, 64, 256, 3, 1),
 ])
-def test_conv_fwd_and_stats(be, dtype, cfg):
+def test_conv_fwd_and_stats(be, stages, dtype, cfg):
     B, H, W, Cin, Cout, k, s = cfg
     x = _rand((B, H, W, Cin), dtype, 1)
     w = _rand((Cout, Cin, k, k), torch.float32, 2) / (Cin * k * k) ** 0.5
@@ -71,7 +80,7 @@ def test_conv_fwd_channel_slices(be, dtype):
     (1, 10, 6, 64, 64, 3, 2),
     (2, 4, 4, 128, 64, 1, 1),
 ])
-def test_conv_dgrad(be, dtype, cfg):
+def test_conv_dgrad(be, stages, dtype, cfg):
     B, H, W, Cin, Cout, k, s = cfg
     w = _rand((Cout, Cin, k, k), torch.float32, 5) / (Cout * k * k) ** 0.5
     wq = w.to(dtype).float()
@@ -88,7 +97,7 @@ def test_conv_dgrad(be, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_linear_bias_gelu_residual(be, dtype):
+def test_linear_bias_gelu_residual(be, stages, dtype):
     M, K, N = 70, 256, 128
     x = _rand((M, K), dtype, 8)
     w = _rand((N, K), torch.float32, 9) / 16.0
