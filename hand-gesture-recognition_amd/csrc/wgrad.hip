@@ -78,8 +78,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     static_assert(BMR * CPRY % NT == 0 && BMR * CPRX % NT == 0, "loader mapping");
 
     MTN_DYN_SMEM(smem);
-    T* const sY = reinterpret_cast<T*>(smem);          // [2][BMR][PY]
-    T* const sX = sY + 2 * BMR * PY;                   // [2][BMR][PX]
+    T* const sY = reinterpret_cast<T*>(smem);          // [BMR][PY]
+    T* const sX = sY + BMR * PY;                       // [BMR][PX]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -140,16 +140,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
 
-    if (steps > 0) {
-        load_tiles(0);
-        store_tiles(0);
-    }
-    __syncthreads();
+    // single LDS buffer + register prefetch (two barriers per step): ~35 KB of LDS per workgroup
+    // -> 4 workgroups per CU, whose load / MFMA phases overlap each other
+    if (steps > 0) load_tiles(0);
     for (int st = 0; st < steps; ++st) {
-        const int cur = st & 1;
+        store_tiles(0);
+        __syncthreads();
         if (st + 1 < steps) load_tiles(st + 1);
-        const T* y = sY + cur * BMR * PY + wm * WM;
-        const T* x = sX + cur * BMR * PX + wn * WN;
+        const T* y = sY + wm * WM;
+        const T* x = sX + wn * WN;
         MTN_UNROLL for (int ks = 0; ks < BMR / KI; ++ks) {
             typename Mma<T>::Frag fa[FM], fb[FN];
             MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFrag<T, TR>::load(y + ks * KI * PY + i * 16, PY, lane);
@@ -157,7 +156,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
             MTN_UNROLL for (int i = 0; i < FM; ++i)
                 MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
         }
-        if (st + 1 < steps) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
@@ -195,7 +193,7 @@ template <class T, int BN, int BC, int WGM, int WGN, bool TR>
 int launch_wgrad(const WgradArgs& p, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int BMR = 128 / (int)sizeof(T);
-    constexpr size_t lds = 2 * (size_t)BMR * ((BN + BC) * sizeof(T) + 2 * PADB);
+    constexpr size_t lds = (size_t)BMR * ((BN + BC) * sizeof(T) + 2 * PADB);
 #ifndef MTN_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -214,21 +212,36 @@ int launch_wgrad(const WgradArgs& p, hipStream_t stream) {
 static int g_use_tr16 = 1;
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
 
-static bool big_tile(int N, int Cin) { return N % 128 == 0 && Cin % 128 == 0; }
+// tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
+static void wgrad_tile(int N, int Cin, int* bn, int* bc) {
+    *bn = N % 128 == 0 ? 128 : 64;
+    *bc = Cin % 128 == 0 ? 128 : 64;
+    if (*bn == 64 && *bc == 128) *bc = 64;          // (64,128) is not instantiated
+}
 
 // pixels per split: multiple of the step size, >= ~4096 rows, but enough splits to fill the chip
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split) {
     const int bmr = dtype == MTN_BF16 ? 64 : 32;
-    const int t = big_tile(N, Cin) ? 128 : 64;
-    const long tiles = (long)(N / t) * (K / t);
+    int bn, bc;
+    wgrad_tile(N, Cin, &bn, &bc);
+    const long tiles = (long)(N / bn) * (K / bc);
     long want = (M + 4095) / 4096;
-    const long fill = (512 + tiles - 1) / tiles;
+    const long fill = (1024 + tiles - 1) / tiles;
     if (want < fill) want = fill;
     long rps = (M + want - 1) / want;
     rps = (rps + bmr - 1) / bmr * bmr;
     if (rps < bmr) rps = bmr;
     *rows_per_split = (int)rps;
     return (int)((M + rps - 1) / rps);
+}
+
+template <class T, bool TR>
+static int wgrad_dispatch(const WgradArgs& p, hipStream_t stream) {
+    int bn, bc;
+    wgrad_tile(p.N, p.Cin, &bn, &bc);
+    if (bn == 128 && bc == 128) return launch_wgrad<T, 128, 128, 2, 2, TR>(p, stream);
+    if (bn == 128) return launch_wgrad<T, 128, 64, 4, 1, TR>(p, stream);
+    return launch_wgrad<T, 64, 64, 2, 2, TR>(p, stream);
 }
 
 int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
@@ -242,15 +255,8 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
                 "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
     int rc;
-    if (big_tile(p.N, p.Cin)) {
-        if (dtype == MTN_BF16) rc = g_use_tr16 ? launch_wgrad<bf16_t, 128, 128, 2, 2, true>(p, stream)
-                                               : launch_wgrad<bf16_t, 128, 128, 2, 2, false>(p, stream);
-        else rc = launch_wgrad<float, 128, 128, 2, 2, false>(p, stream);
-    } else {
-        if (dtype == MTN_BF16) rc = g_use_tr16 ? launch_wgrad<bf16_t, 64, 64, 2, 2, true>(p, stream)
-                                               : launch_wgrad<bf16_t, 64, 64, 2, 2, false>(p, stream);
-        else rc = launch_wgrad<float, 64, 64, 2, 2, false>(p, stream);
-    }
+    if (dtype == MTN_BF16) rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
+    else rc = wgrad_dispatch<float, false>(p, stream);
     if (rc) return rc;
     const long total = (long)p.N * p.K;
     const int blocks = (int)((total + 63) / 64);
