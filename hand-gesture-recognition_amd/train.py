@@ -128,10 +128,14 @@ class TrainStep:
         mdl = self.model
         ops.adamw_step(mdl.flat_params, mdl.flat_grads, self.m, self.v, self.state)
 
-    def _eager(self, img, label, target, tw):
-        self._fwd_bwd(img, label, target, tw)
+    def _sync_grads(self):
+        """One bucket: RCCL all-reduce (sum) of the flat gradient buffer; AdamW applies 1/world."""
         if self.world > 1:
             dist.all_reduce(self.model.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _eager(self, img, label, target, tw):
+        self._fwd_bwd(img, label, target, tw)
+        self._sync_grads()
         self._update()
         return self.eng.losses
 
@@ -176,7 +180,7 @@ class TrainStep:
                 dst.copy_(src, non_blocking=True)
         self._graph[0].replay()
         if self.world > 1:
-            dist.all_reduce(self.model.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+            self._sync_grads()
             self._graph[1].replay()
         return self.eng.losses
 
