@@ -23,7 +23,9 @@
 namespace {
 
 constexpr int HD = 32;                       // head_dim (model/multitasknet.py:21)
-template <class T> struct Lay { static constexpr int PITCH = HD + 16 / (int)sizeof(T); };
+// LDS row pitch: bf16 rows are padded by 16 bytes (conflict-free fragment reads); the fp32
+// validation mode keeps rows unpadded so that K and V of a 577-token head (384x384) still fit.
+template <class T> struct Lay { static constexpr int PITCH = sizeof(T) == 2 ? HD + 8 : HD; };
 
 // ---- operand over the head_dim axis of one row (A: [row][k], B: [k][col]) ----------------------
 template <class T> struct RowOp;
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const int NP = (N + 31) & ~31, nkt = (N + 15) / 16, nqp = NP / 32;
     T* sQ = reinterpret_cast<T*>(smem);
     T* sD = sQ + NP * PITCH;
+    constexpr bool kStageRows = sizeof(T) == 2;                 // fp32 mode reads lse / delta from global
     float* sL = reinterpret_cast<float*>(sD + NP * PITCH);      // lse[NP]
     float* sDl = sL + NP;                                       // delta[NP]
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -274,10 +277,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const long row0 = (long)b * N;
     stage_head<T>(sQ, qkv, ld, h * HD, row0, N, NP);
     stage_head<T>(sD, dout, ldo, h * HD, row0, N, NP);
-    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-        sL[i] = i < N ? lse[(long)bh * N + i] : 0.f;
-        sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
-    }
+    if (kStageRows)
+        for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+            sL[i] = i < N ? lse[(long)bh * N + i] : 0.f;
+            sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
+        }
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     for (int kt = wid; kt < nkt; kt += 4) {
@@ -300,9 +304,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
                     const int q = qb + 4 * g + r;
                     const bool ok = kok && q < N;
-                    const float pv = ok ? __expf(s[r] * scale - sL[q]) : 0.f;
+                    const float lq = kStageRows ? sL[q] : (q < N ? lse[(long)bh * N + q] : 0.f);
+                    const float dq = kStageRows ? sDl[q] : (q < N ? delta[(long)bh * N + q] : 0.f);
+                    const float pv = ok ? __expf(s[r] * scale - lq) : 0.f;
                     p[hf][r] = pv;
-                    ds[hf][r] = pv * (dp[r] - sDl[q]) * scale;
+                    ds[hf][r] = pv * (dp[r] - dq) * scale;
                 }
             }
             dv0 = acc_mma(sD + qp * 32 * PITCH, PITCH, p[0], p[1], dv0, lane);          // dV^T += dO^T P
@@ -357,7 +363,7 @@ int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
     }
     int rc = mtn_check_launch("attn_bwd_dq");
     if (rc) return rc;
-    const size_t lds2 = lds + 2 * (size_t)NP * sizeof(float);
+    const size_t lds2 = lds + (sizeof(T) == 2 ? 2 * (size_t)NP * sizeof(float) : 0);
     set_max_lds(attn_bwd_dkv_kernel<T>, lds2);
     MTN_LAUNCH((attn_bwd_dkv_kernel<T>), grid, block, lds2, stream, (const T*)a.qkv, (const T*)a.dout, a.lse, a.delta,
                (T*)a.dqkv, a.N, a.H, a.scale);
@@ -369,7 +375,7 @@ int check_attn(const AttnArgs& a, int dtype) {
     MTN_REQUIRE(a.B > 0 && a.H > 0 && a.N > 0 && a.D == HD, "attention: head_dim must be %d (got %d)", HD, a.D);
     const int NP = (a.N + 31) & ~31;
     MTN_REQUIRE(NP / 16 <= 38, "attention: N=%d exceeds the register-resident limit 608", a.N);
-    const size_t lds = 2 * (size_t)NP * (HD * (dtype == MTN_BF16 ? 2 : 4) + 16) + 2 * (size_t)NP * 4;
+    const size_t lds = dtype == MTN_BF16 ? 2 * (size_t)NP * (HD * 2 + 16) + 2 * (size_t)NP * 4 : 2 * (size_t)NP * HD * 4;
     MTN_REQUIRE(lds <= 160 * 1024, "attention: N=%d does not fit LDS in this dtype (%zu bytes)", a.N, lds);
     return MTN_OK;
 }

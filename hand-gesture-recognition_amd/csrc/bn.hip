@@ -230,24 +230,35 @@ inline int ew_grid(long total) {
 static const int kRowsPerBlock = 128;     // rows folded by one rowblock_sum block
 static const int kBwdRows = 256;          // rows per bn_bwd_reduce block (upper bound, see below)
 
-int mtn_reduce_rows_needed(int rows) { return rows > kRowsPerBlock ? rows + mtn_cdiv(rows, kRowsPerBlock) : rows; }
+// rows of scratch a slab with `rows` producer rows needs for the folding passes (appended after it)
+int mtn_reduce_rows_needed(int rows) {
+    int total = rows;
+    while (rows > kRowsPerBlock) {
+        rows = mtn_cdiv(rows, kRowsPerBlock);
+        total += rows;
+    }
+    return total;
+}
 
-// reduces part[rows][W] in place-adjacent scratch; returns pointer/rows of the (small) slab to finalize
+// folds part[rows][W] 128 rows at a time into the scratch rows that follow it until <= 128 rows
+// remain; returns pointer / row count of the small slab the finalize kernel reads
 static int fold_rows(const float*& part, int& rows, int W, hipStream_t stream) {
-    if (rows <= kRowsPerBlock) return MTN_OK;
-    const int R = mtn_cdiv(rows, kRowsPerBlock);
-    float* out = const_cast<float*>(part) + (long)rows * W;
-    MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(256), 0, stream, part, rows, W, kRowsPerBlock, out);
-    part = out;
-    rows = R;
-    return mtn_check_launch("rowblock_sum");
+    while (rows > kRowsPerBlock) {
+        const int R = mtn_cdiv(rows, kRowsPerBlock);
+        float* out = const_cast<float*>(part) + (long)rows * W;
+        MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(256), 0, stream, part, rows, W, kRowsPerBlock, out);
+        int rc = mtn_check_launch("rowblock_sum");
+        if (rc) return rc;
+        part = out;
+        rows = R;
+    }
+    return MTN_OK;
 }
 
 int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float* gamma, const float* beta,
                         float* rmean, float* rvar, long long* nbt, float momentum, float eps, float* scale_shift,
                         float* mean_rstd, hipStream_t stream) {
     MTN_REQUIRE(tiles > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
-    MTN_REQUIRE(tiles <= kRowsPerBlock * kRowsPerBlock, "bn_finalize: too many stat tiles (%d)", tiles);
     const float* part = stats;
     int rows = tiles;
     int rc = fold_rows(part, rows, 2 * C, stream);
@@ -288,7 +299,6 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
     MTN_REQUIRE(a.act == MTN_ACT_NONE || a.act == MTN_ACT_SILU, "bn_bwd: act=%d", a.act);
     MTN_REQUIRE(a.act == MTN_ACT_SILU || !a.res, "bn_bwd: residual needs SiLU");
     const int blocks = mtn_bn_bwd_blocks(a.M);
-    MTN_REQUIRE(blocks <= kRowsPerBlock * kRowsPerBlock, "bn_bwd: M too large");
     const size_t lds = (size_t)(256 / cpr) * 2 * a.C * sizeof(float);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)a.dout, a.lddo,
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }  // namespace
 
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream) {
-    MTN_REQUIRE(rows > 0 && W > 0 && rows <= kRowsPerBlock * kRowsPerBlock, "colsum: bad sizes (%d x %d)", rows, W);
+    MTN_REQUIRE(rows > 0 && W > 0, "colsum: bad sizes (%d x %d)", rows, W);
     const float* part = slab;
     int rc = fold_rows(part, rows, W, stream);
     if (rc) return rc;

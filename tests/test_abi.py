@@ -1,0 +1,35 @@
+"""The C-ABI library loads and exports every symbol include/mtn.h declares (no GPU needed)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mtn.h")).read()
+    return sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(mtn_\w+)\s*\(", src, re.M)))
+
+
+def test_header_and_binding_agree():
+    from hand_gesture_recognition_amd import lib
+    assert _declared() == sorted(lib.exported_symbols())
+
+
+@pytest.mark.parametrize("which", ["hip", "emu"])
+def test_library_exports_every_declared_symbol(which):
+    import ctypes
+    from hand_gesture_recognition_amd import lib
+    path = lib.HIP_LIB if which == "hip" else os.path.join(os.path.dirname(lib.HIP_LIB), "libmtn_emu.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "hand-gesture-recognition_amd", "csrc"), "-j8", which],
+                       check=True, stdout=subprocess.DEVNULL)
+    dll = ctypes.CDLL(path)
+    for name in _declared():
+        assert hasattr(dll, name), name
+    lib.use_library(path)                     # binds all prototypes; raises on a missing symbol
+    assert lib.call("mtn_abi_version") == 1
+    with pytest.raises(RuntimeError, match="ksize"):
+        lib.call("mtn_conv_fwd", 0, 0, 0, 0, 0, 0, 0, 1, 8, 8, 64, 64, 5, 1, 0)   # argument check, no launch
