@@ -113,11 +113,14 @@ __global__ __launch_bounds__(256) void pose_fwd_kernel(const T* __restrict__ tok
 // Interpolation coordinates come from per-block LDS tables (PyTorch's align_corners=True map).
 // slab row b = [dW (J*256) | dbias (J)].
 constexpr int RB = 4;
-template <class T, int CC>
+constexpr int MAXTAP = 12;      // an output column range of at most 2*4+2 touches one source column at scale 4
+template <class T, int CC, int JT>     // JT = compile-time joint count (0: runtime J <= MAXJ)
 __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                        const float* __restrict__ dhm, T* __restrict__ dtok,
-                                                       float* __restrict__ slab, int h, int w, int J) {
+                                                       float* __restrict__ slab, int h, int w, int Jrt) {
     constexpr int PL = 256 / CC;
+    constexpr int JL = JT ? JT : MAXJ;                  // unrolled loop bound
+    const int J = JT ? JT : Jrt;
     MTN_DYN_SMEM(smem);
     const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW, RP = RB * OW;
     float* sS = reinterpret_cast<float*>(smem);         // source tokens [hw][CC]
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
     float* tW = reinterpret_cast<float*>(tI1 + OH + OW);
     int* tLo = reinterpret_cast<int*>(tW + OH + OW);    // [w] first / last output column touching a source column
     int* tHi = tLo + w;
+    float* tTap = reinterpret_cast<float*>(tHi + w);    // [w][MAXTAP] x-weights of output columns lo.. on column sx
     const int b = blockIdx.y, c0 = blockIdx.x * CC;
     const int c = threadIdx.x % CC, pl = threadIdx.x / CC;
     const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + c0;
@@ -148,9 +152,19 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
         for (int ox = 0; ox < OW; ++ox)
             if (tI0[OH + ox] == sx || tI1[OH + ox] == sx) { if (ox < lo) lo = ox; hi = ox; }
         tLo[sx] = lo; tHi[sx] = hi;
+        for (int k = 0; k < MAXTAP; ++k) {
+            const int ox = lo + k;
+            float wgt = 0.f;
+            if (ox <= hi) {
+                const int x0 = tI0[OH + ox], x1 = tI1[OH + ox];
+                const float wx = tW[OH + ox];
+                wgt = (x0 == sx ? 1.f - wx : 0.f) + ((x1 == sx && x1 != x0) ? wx : 0.f);
+            }
+            tTap[sx * MAXTAP + k] = wgt;
+        }
     }
-    float wj[MAXJ], dw[MAXJ], db[MAXJ];
-    MTN_UNROLL for (int j = 0; j < MAXJ; ++j) { wj[j] = j < J ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; db[j] = 0.f; }
+    float wj[JL], dw[JL], db[JL];
+    MTN_UNROLL for (int j = 0; j < JL; ++j) { wj[j] = (JT || j < J) ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; db[j] = 0.f; }
     const float* dh = dhm + (long)b * J * OHW;
     const bool do_bias = blockIdx.x == 0;
     for (int r0 = 0; r0 < OH; r0 += RB) {
@@ -162,8 +176,8 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
         __syncthreads();
         if (do_bias) {
             for (int p = threadIdx.x; p < RP; p += 256)
-                MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
-                    if (j < J) db[j] += sD[j * RP + p];
+                MTN_UNROLL for (int j = 0; j < JL; ++j)
+                    if (JT || j < J) db[j] += sD[j * RP + p];
         }
         // phase 1
         for (int gq = pl; gq < RP / 4; gq += PL) {
@@ -179,8 +193,8 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
                            wy * ((1.f - wx) * sS[(y1 + x0) * CC + c] + wx * sS[(y1 + x1) * CC + c]);
                     gs[e] = 0.f;
                 }
-                MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
-                    if (j < J) {
+                MTN_UNROLL for (int j = 0; j < JL; ++j) {
+                    if (JT || j < J) {
                         const float4 d = *reinterpret_cast<const float4*>(sD + j * RP + p0);
                         const float ww = wj[j];
                         gs[0] += d.x * ww; gs[1] += d.y * ww; gs[2] += d.z * ww; gs[3] += d.w * ww;
@@ -196,14 +210,11 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
         // phase 2: thread (c, owner pl) owns source columns pl, pl+PL, ...
         for (int sx = pl; sx < w; sx += PL) {
             const int lo = tLo[sx], hi = tHi[sx];
+            const int nt = hi - lo + 1;
             for (int r = 0; r < RB && r0 + r < OH; ++r) {
                 float sum = 0.f;
-                for (int ox = lo; ox <= hi; ++ox) {
-                    const int x0 = tI0[OH + ox], x1 = tI1[OH + ox];
-                    const float wx = tW[OH + ox];
-                    const float wgt = (x0 == sx ? 1.f - wx : 0.f) + ((x1 == sx && x1 != x0) ? wx : 0.f);
-                    sum += wgt * sU[(r * OW + ox) * CC + c];
-                }
+                const float* up = sU + (r * OW + lo) * CC + c;
+                for (int k = 0; k < nt; ++k) sum += tTap[sx * MAXTAP + k] * up[k * CC];
                 const int oy = r0 + r;
                 const float wy = tW[oy];
                 sG[(tI0[oy] * w + sx) * CC + c] += (1.f - wy) * sum;
@@ -212,8 +223,8 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
         }
     }
     __syncthreads();
-    MTN_UNROLL for (int j = 0; j < MAXJ; ++j)
-        if (j < J) sD[(pl * J + j) * CC + c] = dw[j];
+    MTN_UNROLL for (int j = 0; j < JL; ++j)
+        if (JT || j < J) sD[(pl * J + j) * CC + c] = dw[j];
     __syncthreads();
     for (int i = threadIdx.x; i < hw * CC; i += 256) {
         const int p = i / CC, cc = i - p * CC;
@@ -229,8 +240,8 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
     if (do_bias) {
         __syncthreads();
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        MTN_UNROLL for (int j = 0; j < MAXJ; ++j) {
-            if (j < J) {
+        MTN_UNROLL for (int j = 0; j < JL; ++j) {
+            if (JT || j < J) {
                 const float t = wave_sum(db[j]);
                 if (lane == 0) sD[wid * J + j] = t;
             }
@@ -324,17 +335,17 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     return mtn_check_launch("pose_fwd");
 }
 
-template <class T, int CC>
+template <class T, int CC, int JT>
 static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, void* dtok, float* slab, int B, int h, int w,
                            int J, hipStream_t stream) {
     const int OH = 4 * h, OW = 4 * w, RP = RB * OW, PL = 256 / CC;
     const size_t tail = (size_t)(J * RP + RP * CC > PL * J * CC ? J * RP + RP * CC : PL * J * CC);
-    const size_t lds = ((size_t)2 * h * w * CC + tail + 3 * (size_t)(OH + OW) + 2 * (size_t)w) * 4;
+    const size_t lds = ((size_t)2 * h * w * CC + tail + 3 * (size_t)(OH + OW) + (2 + MAXTAP) * (size_t)w) * 4;
     MTN_REQUIRE(lds <= 160 * 1024, "pose_bwd: feature map %dx%d too large for LDS (%zu bytes)", h, w, lds);
 #ifndef MTN_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC, JT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
-    MTN_LAUNCH((pose_bwd_kernel<T, CC>), dim3(DIM / CC, B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
+    MTN_LAUNCH((pose_bwd_kernel<T, CC, JT>), dim3(DIM / CC, B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
     return mtn_check_launch("pose_bwd");
 }
 
@@ -344,8 +355,13 @@ int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dt
                      int dtype, int B, int h, int w, int J, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
     int rc;       // 16-channel chunks: ~48 KB of LDS at 12x12 tokens -> 3 workgroups per CU hide the LDS latency
-    if (dtype == MTN_BF16) rc = pose_bwd_launch<bf16_t, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
-    else rc = pose_bwd_launch<float, 16>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    if (J == 21) {      // hagrid.yaml: num_joints = 21 -> fully unrolled joint loops
+        if (dtype == MTN_BF16) rc = pose_bwd_launch<bf16_t, 16, 21>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+        else rc = pose_bwd_launch<float, 16, 21>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    } else {
+        if (dtype == MTN_BF16) rc = pose_bwd_launch<bf16_t, 16, 0>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+        else rc = pose_bwd_launch<float, 16, 0>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
+    }
     if (rc) return rc;
     return mtn_colsum_run(slab, B, J * (DIM + 1), dW_dbias, stream);
 }

@@ -140,7 +140,7 @@ def test_cls_head(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (2, 12, 12, 21)])
+@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (2, 12, 12, 21), (1, 2, 3, 17)])
 def test_pose_head(be, dtype, cfg):
     B, h, w, J = cfg
     if be.name == "emu" and h * w > 50:
