@@ -111,6 +111,16 @@ __device__ __forceinline__ void stage_head(T* dst, const T* __restrict__ src, in
     }
 }
 
+// XCD-aware (batch, head) order: the H heads of one image read interleaved 64-byte slices of the
+// same qkv rows (two heads per 128-byte line); give all heads of an image to one XCD group
+// (workgroup id % 8) so those lines are fetched into one L2 once.
+__device__ __forceinline__ int attn_bh(int H) {
+    const int L = blockIdx.x, B = gridDim.x / H;
+    if (B % 8 != 0) return L;
+    const int b = (L / (8 * H)) * 8 + (L & 7), h = (L >> 3) % H;
+    return b * H + h;
+}
+
 template <class T> __device__ __forceinline__ void store4(T* dst, f32x4_t v);
 template <> __device__ __forceinline__ void store4<float>(float* dst, f32x4_t v) {
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const int NP = (N + 31) & ~31, nkt = NP / 16, nqt = (N + 15) / 16;
     T* sK = reinterpret_cast<T*>(smem);
     T* sV = sK + NP * PITCH;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
     const int ld = 3 * H * HD;
     const long row0 = (long)b * N;
     stage_head<T>(sK, qkv, ld, H * HD + h * HD, row0, N, NP);
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     const int NP = (N + 31) & ~31, nkt = NP / 16, nqt = (N + 15) / 16;
     T* sK = reinterpret_cast<T*>(smem);
     T* sV = sK + NP * PITCH;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
     const int ld = 3 * H * HD, ldo = H * HD;
     const long row0 = (long)b * N;
     stage_head<T>(sK, qkv, ld, H * HD + h * HD, row0, N, NP);
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     constexpr bool kStageRows = sizeof(T) == 2;                 // fp32 mode reads lse / delta from global
     float* sL = reinterpret_cast<float*>(sD + NP * PITCH);      // lse[NP]
     float* sDl = sL + NP;                                       // delta[NP]
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
     const int ld = 3 * H * HD, ldo = H * HD;
     const long row0 = (long)b * N;
     stage_head<T>(sQ, qkv, ld, h * HD, row0, N, NP);

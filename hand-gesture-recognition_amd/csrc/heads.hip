@@ -134,7 +134,16 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
     int* tLo = reinterpret_cast<int*>(tW + OH + OW);    // [w] first / last output column touching a source column
     int* tHi = tLo + w;
     float* tTap = reinterpret_cast<float*>(tHi + w);    // [w][MAXTAP] x-weights of output columns lo.. on column sx
-    const int b = blockIdx.y, c0 = blockIdx.x * CC;
+    // XCD-aware order: the DIM/CC channel-chunk workgroups of one image all stream the same heat-map
+    // gradient; keep them on one XCD group (id % 8) and adjacent in time so it is fetched once.
+    constexpr int NCH = DIM / CC;
+    int b, chunk;
+    {
+        const int L = blockIdx.x, B = gridDim.x / NCH;
+        if (B % 8 == 0) { const int xcd = L & 7, j = L >> 3; b = (j / NCH) * 8 + xcd; chunk = j % NCH; }
+        else { b = L / NCH; chunk = L % NCH; }
+    }
+    const int c0 = chunk * CC;
     const int c = threadIdx.x % CC, pl = threadIdx.x / CC;
     const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + c0;
     for (int i = threadIdx.x; i < hw * CC; i += 256) {
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
     float wj[JL], dw[JL], db[JL];
     MTN_UNROLL for (int j = 0; j < JL; ++j) { wj[j] = (JT || j < J) ? W[j * DIM + c0 + c] : 0.f; dw[j] = 0.f; db[j] = 0.f; }
     const float* dh = dhm + (long)b * J * OHW;
-    const bool do_bias = blockIdx.x == 0;
+    const bool do_bias = chunk == 0;
     for (int r0 = 0; r0 < OH; r0 += RB) {
         __syncthreads();
         for (int i = threadIdx.x; i < J * RP; i += 256) {
@@ -345,7 +354,7 @@ static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, vo
 #ifndef MTN_EMU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_kernel<T, CC, JT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
-    MTN_LAUNCH((pose_bwd_kernel<T, CC, JT>), dim3(DIM / CC, B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
+    MTN_LAUNCH((pose_bwd_kernel<T, CC, JT>), dim3((DIM / CC) * B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J);
     return mtn_check_launch("pose_bwd");
 }
 

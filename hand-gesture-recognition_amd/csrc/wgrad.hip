@@ -84,14 +84,30 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
 
-    // blockIdx.x = (n-tile, k-tile) fastest, blockIdx.y = split
+    // XCD-aware order: the (n-tile, tap/ci-tile) workgroups of ONE pixel split re-read the same dY /
+    // X rows (9 taps x N/BN tiles), so they must share an L2.  Workgroups are dealt round-robin
+    // over the 8 XCDs (id % 8 labels the XCD group): XCD group x walks splits x, x+8, ... and runs
+    // the tiles of a split back to back.  (PMC: without this the 64x64-tile layers pulled 1.25 GB
+    // per launch through the fabric, 8x their operands.)
     const int tiles_n = p.N / BN;
-    const int tile_n = blockIdx.x % tiles_n, tile_k = blockIdx.x / tiles_n;
+    const int tiles = tiles_n * (p.K / BC);
+    int tile, split;
+    {
+        const int L = blockIdx.x;
+        if (p.splits % 8 == 0 && tiles <= 24) {       // many-tile layers already share operands within an XCD
+            const int xcd = L & 7, j = L >> 3;
+            split = (j / tiles) * 8 + xcd;
+            tile = j % tiles;
+        } else {
+            split = L / tiles;
+            tile = L % tiles;
+        }
+    }
+    const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
     const int n0 = tile_n * BN;
     const int kcol0 = tile_k * BC;                     // column in [0, K)
     const int tap = kcol0 / p.Cin, c0 = kcol0 - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int split = blockIdx.y;
     const long m_begin = (long)split * p.rows_per_split;
     long m_end = m_begin + p.rows_per_split;
     if (m_end > p.M) m_end = p.M;
@@ -203,7 +219,7 @@ int launch_wgrad(const WgradArgs& p, hipStream_t stream) {
     }
 #endif
     const int tiles = (p.N / BN) * (p.K / BC);
-    MTN_LAUNCH((wgrad_kernel<T, BN, BC, WGM, WGN, TR>), dim3(tiles, p.splits), dim3(NT), lds, stream, p);
+    MTN_LAUNCH((wgrad_kernel<T, BN, BC, WGM, WGN, TR>), dim3(tiles * p.splits), dim3(NT), lds, stream, p);
     return mtn_check_launch("wgrad");
 }
 
@@ -232,7 +248,9 @@ int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_spli
     rps = (rps + bmr - 1) / bmr * bmr;
     if (rps < bmr) rps = bmr;
     *rows_per_split = (int)rps;
-    return (int)((M + rps - 1) / rps);
+    long splits = (M + rps - 1) / rps;
+    if (splits >= 8) splits = (splits + 7) / 8 * 8;        // whole splits per XCD group (empty ones add zeros)
+    return (int)splits;
 }
 
 template <class T, bool TR>

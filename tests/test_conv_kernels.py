@@ -121,6 +121,7 @@ def test_linear_bias_gelu_residual(be, stages, dtype):
     (1, 8, 8, 64, 128, 3, 2),
     (3, 5, 7, 128, 128, 1, 1),
     (5, 4, 4, 128, 128, 3, 1),
+    (1, 20, 30, 64, 64, 1, 1),       # >= 8 pixel splits: exercises the XCD-group split order
 ])
 def test_conv_wgrad(be, dtype, tr16, cfg):
     from hand_gesture_recognition_amd import lib

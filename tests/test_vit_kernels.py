@@ -83,7 +83,7 @@ def _attn_ref(qkv, B, N, H, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 5, 2), (1, 37, 8), (1, 145, 2), (1, 200, 1)])
+@pytest.mark.parametrize("cfg", [(2, 5, 2), (1, 37, 8), (8, 5, 2), (1, 145, 2), (1, 200, 1)])
 def test_attention_fwd_bwd(be, dtype, cfg):
     B, N, H = cfg
     D = 32
@@ -140,7 +140,7 @@ def test_cls_head(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (2, 12, 12, 21), (1, 2, 3, 17)])
+@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17)])
 def test_pose_head(be, dtype, cfg):
     B, h, w, J = cfg
     if be.name == "emu" and h * w > 50:
