@@ -242,7 +242,7 @@ int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_spli
     wgrad_tile(N, Cin, &bn, &bc);
     const long tiles = (long)(N / bn) * (K / bc);
     long want = (M + 4095) / 4096;
-    const long fill = (1024 + tiles - 1) / tiles;
+    const long fill = (512 + tiles - 1) / tiles;
     if (want < fill) want = fill;
     long rps = (M + want - 1) / want;
     rps = (rps + bmr - 1) / bmr * bmr;
