@@ -28,11 +28,30 @@
 namespace {
 
 constexpr int ROW_BYTES = 128;          // reduction bytes per row per K step
-constexpr int PITCH_BYTES = 144;        // padded LDS row
+constexpr int PITCH_BYTES = 144;        // padded LDS row (register-staged pipelines)
+
+// rows that fall into the zero padding of a convolution read this page instead (LDS-DMA cannot
+// write zeros by itself)
+__device__ unsigned g_zero_page[64];
+
+// One wave-instruction of LDS-DMA: lane l copies 16 bytes from its own global address to
+// lds_block + 16*l (the destination is wave-uniform base + lane*16 -- cdna_hip_programming.md
+// section 5, "Async global->LDS copy"); no VGPR staging, no ds_write.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
+#ifdef MTN_EMU
+    std::memcpy(static_cast<char*>(lds_block) + 16 * (threadIdx.x & 63), gsrc, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_block, 16, 0, 0);
+#endif
+}
 
 // STAGES = 2: double-buffered LDS, one barrier per K step, f32 C staging (2 workgroups / CU).
 // STAGES = 1: single LDS buffer + register prefetch, two barriers per K step, C staged in T:
 //             half the LDS -> 4 workgroups / CU, whose main loops / epilogues overlap each other.
+// STAGES = 3: LDS-DMA (global_load_lds 16 B) into two unpadded, XOR-swizzled LDS buffers: the
+//             swizzle is applied to the per-lane SOURCE chunk and to the fragment read, the LDS
+//             image itself is lane-linear (rule 21).  One barrier per K step, no staging VGPRs.
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
@@ -45,13 +64,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int RA = BM * 8 / NT;      // A chunks per thread per K step
     constexpr int RB = BN * 8 / NT;      // W chunks per thread per K step
     constexpr int RSTEP = NT / 8;        // rows between a thread's chunks
-    typedef typename std::conditional<STAGES == 1, T, float>::type CT;     // staged C element
+    typedef typename std::conditional<STAGES != 2, T, float>::type CT;     // staged C element
+    constexpr bool DMA = STAGES >= 3;
+    constexpr int NBUF = STAGES == 1 ? 1 : (STAGES == 4 ? 3 : 2);
+    constexpr int PITCH_E = DMA ? BK : PITCH;                              // LDS row pitch in elements
     constexpr int CP = BN + 16 / (int)sizeof(CT);                          // pitch of the staged C tile
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "loader mapping");
 
     MTN_DYN_SMEM(smem);
-    T* const sA = reinterpret_cast<T*>(smem);                       // [STAGES][BM][PITCH]
-    T* const sB = sA + STAGES * BM * PITCH;                         // [STAGES][BN][PITCH]
+    T* const sA = reinterpret_cast<T*>(smem);                       // [NBUF][BM][PITCH_E]
+    T* const sB = sA + NBUF * BM * PITCH_E;                         // [NBUF][BN][PITCH_E]
     CT* const sC = reinterpret_cast<CT*>(smem);                     // [BM][CP] (after the K loop)
 
     const int tid = threadIdx.x;
@@ -94,13 +116,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             ox = rem - oy * p.OW;
         }
     };
-    const int chunk = tid & 7;
-    const int row0 = tid >> 3;
+    // row/chunk owned by this thread in each of its RA (RB) loads.  Register staging: rows
+    // tid/8 + 32 i, chunk tid%8.  LDS-DMA: wave w, instruction i fills the 1 KiB block of rows
+    // 8*(w*RA+i).., lane l lands at (row l/8, slot l%8) and FETCHES chunk slot ^ (row & 7).
+    const int chunk = DMA ? ((lane & 7) ^ ((lane >> 3) & 7)) : (tid & 7);
+    const int row0 = DMA ? (wid * RA * 8 + (lane >> 3)) : (tid >> 3);
+    const int rstep_a = DMA ? 8 : RSTEP;
+    const int brow0 = DMA ? (wid * RB * 8 + (lane >> 3)) : (tid >> 3);
+    const int rstep_b = DMA ? 8 : RSTEP;
     const int dshift = p.div >> 1, dmask = p.div - 1;     // div in {1,2}
     int a_y[RA], a_x[RA], a_base[RA];
     unsigned my_taps = 0;
     MTN_UNROLL for (int i = 0; i < RA; ++i) {
-        const int m = m0 + row0 + i * RSTEP;
+        const int m = m0 + row0 + i * rstep_a;
         if (m < p.M) {
             int b, oy, ox;
             decode(m, b, oy, ox);
@@ -154,9 +182,29 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             }
         }
         MTN_UNROLL for (int i = 0; i < RB; ++i) {
-            const long off = (long)(n0 + row0 + i * RSTEP) * p.K + k0 + chunk * VEC;
+            const long off = (long)(n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC;
             rb[i] = *reinterpret_cast<const chunk16*>(gW + off);
         }
+    };
+    // LDS-DMA issue of K step kt into buffer `stage` (no registers, no LDS stores)
+    auto dma_tiles = [&](int kt, int stage) {
+        const int ti = kt / spt, c0 = (kt - ti * spt) * BK;
+        const int tap = (int)((tap_list >> (4 * ti)) & 15ull);
+        const int k0 = tap * p.Cin + c0;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        char* a = reinterpret_cast<char*>(sA + stage * BM * PITCH_E);
+        char* b = reinterpret_cast<char*>(sB + stage * BN * PITCH_E);
+        MTN_UNROLL for (int i = 0; i < RA; ++i) {
+            const int ty = a_y[i] + kh * p.sgn, tx = a_x[i] + kw * p.sgn;
+            const int iy = ty >> dshift, ix = tx >> dshift;
+            const bool ok = (ty >= 0) && (tx >= 0) && ((ty & dmask) == 0) && ((tx & dmask) == 0) &&
+                            (iy < p.H) && (ix < p.W);
+            const void* src = ok ? static_cast<const void*>(gA + (long)(a_base[i] + iy * p.W + ix) * p.lda + c0 + chunk * VEC)
+                                 : static_cast<const void*>(g_zero_page);
+            glds16(src, a + (wid * RA + i) * 1024);
+        }
+        MTN_UNROLL for (int i = 0; i < RB; ++i)
+            glds16(gW + (long)(n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC, b + (wid * RB + i) * 1024);
     };
     auto store_tiles = [&](int stage) {
         T* a = sA + stage * BM * PITCH;
@@ -176,6 +224,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     const int fk = (lane >> 4) * (KI / 4);
 
     auto compute = [&](int stage) {
+        if (DMA) {
+            // fragment element offset ks*KI+fk -> 16-byte slot (ks*KI+fk)/VEC, swizzled by row & 7
+            const T* a = sA + stage * BM * BK + (wm * WM + frow) * BK;
+            const T* b = sB + stage * BN * BK + (wn * WN + frow) * BK;
+            const int sw = frow & 7;                       // (row & 7): tile bases are multiples of 16
+            MTN_UNROLL for (int ks = 0; ks < BK / KI; ++ks) {
+                const int e = ks * KI + fk;
+                const int off = (((e / VEC) ^ sw) * VEC) + (e % VEC);
+                typename Mma<T>::Frag fa[FM], fb[FN];
+                MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = Mma<T>::load(a + i * 16 * BK + off);
+                MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = Mma<T>::load(b + j * 16 * BK + off);
+                MTN_UNROLL for (int i = 0; i < FM; ++i)
+                    MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+            }
+            return;
+        }
         const T* a = sA + stage * BM * PITCH + (wm * WM + frow) * PITCH + fk;
         const T* b = sB + stage * BN * PITCH + (wn * WN + frow) * PITCH + fk;
         MTN_UNROLL for (int ks = 0; ks < BK / KI; ++ks) {
@@ -186,6 +250,46 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
                 MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
         }
     };
+    if (STAGES == 4) {
+        // three buffers, loads TWO tiles ahead: a counted vmcnt leaves the youngest tile in flight
+        // across a raw s_barrier (a __syncthreads() here would drain it: its fence waits vmcnt(0))
+        if (KT > 0) dma_tiles(0, 0);
+        if (KT > 1) dma_tiles(1, 1);
+#ifndef MTN_EMU
+        if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#else
+        __syncthreads();
+#endif
+        int cur = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            int nxt2 = cur + 2;
+            if (nxt2 >= 3) nxt2 -= 3;
+            if (kt + 2 < KT) dma_tiles(kt + 2, nxt2);
+            compute(cur);
+#ifndef MTN_EMU
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#else
+            __syncthreads();
+#endif
+            cur = cur + 1 == 3 ? 0 : cur + 1;
+        }
+        __syncthreads();
+    } else if (DMA) {
+        // tile kt+1 streams into the other buffer while tile kt is multiplied; the barrier's
+        // vmcnt(0) is exactly the wait the next step needs (one tile in flight)
+        if (KT > 0) dma_tiles(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) dma_tiles(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else
     if (STAGES == 2) {
         if (KT > 0) {
             load_tiles(0);
@@ -276,8 +380,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
 int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
-    constexpr size_t lds_ab = STAGES * (size_t)(BM + BN) * PITCH_BYTES;
-    constexpr size_t csz = STAGES == 1 ? sizeof(T) : 4;
+    constexpr size_t lds_ab = STAGES >= 3 ? (STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
+    constexpr size_t csz = STAGES != 2 ? sizeof(T) : 4;
     constexpr size_t lds_c = (size_t)BM * (BN * csz + 16);
     constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
     constexpr size_t lds0 = lds_ab > lds_c ? lds_ab : lds_c;
@@ -295,21 +399,26 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     return mtn_check_launch("igemm");
 }
 
-static int g_igemm_stages = 1;
+static int g_igemm_stages = 3;   // LDS-DMA double buffer (measured fastest: see DESIGN.md section 4)
+
+template <class T, int BM, int BN, int WGM, int WGN>
+int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
+    if (g_igemm_stages == 4) return launch_igemm<T, BM, BN, WGM, WGN, 4>(p, stream);
+    if (g_igemm_stages == 3) return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
+    if (g_igemm_stages == 2) return launch_igemm<T, BM, BN, WGM, WGN, 2>(p, stream);
+    return launch_igemm<T, BM, BN, WGM, WGN, 1>(p, stream);
+}
 
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
-    const bool one = g_igemm_stages == 1;
-    if (p.N % 128 == 0 && p.M >= 128 * 64)
-        return one ? launch_igemm<T, 128, 128, 2, 2, 1>(p, stream) : launch_igemm<T, 128, 128, 2, 2, 2>(p, stream);
-    if (p.N % 128 == 0)
-        return one ? launch_igemm<T, 64, 128, 1, 4, 1>(p, stream) : launch_igemm<T, 64, 128, 1, 4, 2>(p, stream);
-    return one ? launch_igemm<T, 128, 64, 4, 1, 1>(p, stream) : launch_igemm<T, 128, 64, 4, 1, 2>(p, stream);
+    if (p.N % 128 == 0 && p.M >= 128 * 64) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
+    if (p.N % 128 == 0) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
+    return launch_igemm_mode<T, 128, 64, 4, 1>(p, stream);
 }
 
 }  // namespace
 
-void mtn_igemm_set_stages(int n) { g_igemm_stages = n == 2 ? 2 : 1; }
+void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 4) ? n : 3; }
 
 int mtn_igemm_tiles_m(int M, int N) {
     if (N % 128 == 0 && M >= 128 * 64) return mtn_cdiv(M, 128);

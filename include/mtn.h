@@ -182,7 +182,8 @@ int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors,
                      int dtype, void* stream);
 
 /* test / tuning hook: key 1 = ds_read_b64_tr_b16 operand reads in wgrad (default 1);
- * key 3 = igemm LDS stages (1: single buffer, 4 workgroups/CU (default); 2: double buffer) */
+ * key 3 = igemm pipeline (1: register-staged single LDS buffer; 2: register-staged double buffer;
+ *         3: LDS-DMA double buffer (default); 4: LDS-DMA triple buffer with counted vmcnt) */
 int mtn_debug_set(int key, int value);
 
 #ifdef __cplusplus

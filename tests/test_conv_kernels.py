@@ -20,13 +20,13 @@ def pack_crsk(w_oihw, dtype):       # dgrad operand [I,kh,kw,O]
     return w_oihw.permute(1, 2, 3, 0).contiguous().to(dtype)
 
 
-@pytest.fixture(params=[1, 2], ids=["lds1", "lds2"])
+@pytest.fixture(params=[1, 2, 3, 4], ids=["lds1", "lds2", "dma2", "dma3"])
 def stages(request, be):
-    """both igemm pipelines: single LDS buffer (default) and double buffer"""
+    """all igemm pipelines: register-staged (1 or 2 LDS buffers) and LDS-DMA (2 buffers = default, 3 buffers)"""
     from hand_gesture_recognition_amd import lib
     lib.call("mtn_debug_set", 3, request.param)
     yield request.param
-    lib.call("mtn_debug_set", 3, 1)
+    lib.call("mtn_debug_set", 3, 3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

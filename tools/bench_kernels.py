@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--filter", default="")
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--stages", type=int, default=1)
+    ap.add_argument("--stages", type=int, default=3)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from hand_gesture_recognition_amd import lib as _lib
