@@ -238,6 +238,26 @@ int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors,
     return mtn_pack_run(src, dst, desc, ntensors, max_elems, dtype, (hipStream_t)stream);
 }
 
+int mtn_heatmap_argmax(const float* hm, float* preds, float* maxvals, int maps, int H, int W, void* stream) {
+    return mtn_hm_argmax_run(hm, preds, maxvals, maps, H, W, (hipStream_t)stream);
+}
+int mtn_pose_accuracy(const float* pred_xy, const float* target_xy, float* acc, int B, int J, int H, int W, float thr,
+                      void* stream) {
+    return mtn_pose_acc_run(pred_xy, target_xy, acc, B, J, H, W, thr, (hipStream_t)stream);
+}
+int mtn_cls_confusion(const float* logits, const long long* label, long long* pred_label, int* cm, int B, int C,
+                      void* stream) {
+    return mtn_cls_confusion_run(logits, label, pred_label, cm, B, C, (hipStream_t)stream);
+}
+int mtn_macro_f1(const int* cm, float* f1, int C, void* stream) { return mtn_macro_f1_run(cm, f1, C, (hipStream_t)stream); }
+int mtn_render_targets(const float* joints, const float* vis, float* target, float* weight, int maps, int HH, int HW,
+                       int img_h, int img_w, int sigma, void* stream) {
+    return mtn_render_targets_run(joints, vis, target, weight, maps, HH, HW, img_h, img_w, sigma, (hipStream_t)stream);
+}
+int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B, int H, int W, void* stream) {
+    return mtn_normalize_image_run(img_hwc_u8, out_nchw, B, H, W, (hipStream_t)stream);
+}
+
 int mtn_debug_set(int key, int value) {
     if (key == 1) { mtn_wgrad_set_tr16(value); return MTN_OK; }
     if (key == 2) { mtn_pose_set_dbg(value); return MTN_OK; }

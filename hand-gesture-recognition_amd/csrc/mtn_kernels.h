@@ -114,3 +114,12 @@ int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, c
                     float* scale_shift, int C, hipStream_t stream);
 void mtn_pose_set_dbg(int v);
 void mtn_igemm_set_stages(int n);
+
+int mtn_hm_argmax_run(const float* hm, float* preds, float* maxvals, int maps, int H, int W, hipStream_t stream);
+int mtn_pose_acc_run(const float* pred, const float* tgt, float* acc, int B, int J, int H, int W, float thr, hipStream_t stream);
+int mtn_cls_confusion_run(const float* logits, const long long* label, long long* pred_label, int* cm, int B, int C,
+                          hipStream_t stream);
+int mtn_macro_f1_run(const int* cm, float* f1, int C, hipStream_t stream);
+int mtn_render_targets_run(const float* joints, const float* vis, float* target, float* weight, int maps, int HH, int HW,
+                           int img_h, int img_w, int sigma, hipStream_t stream);
+int mtn_normalize_image_run(const unsigned char* img, float* out, int B, int H, int W, hipStream_t stream);

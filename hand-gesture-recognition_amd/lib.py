@@ -52,6 +52,12 @@ _PROTOS = {
     "mtn_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mtn_adamw_step": [_vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "mtn_pack_weights": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_heatmap_argmax": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_pose_accuracy": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "mtn_cls_confusion": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mtn_macro_f1": [_vp, _vp, _i, _vp],
+    "mtn_render_targets": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mtn_normalize_image": [_vp, _vp, _i, _i, _i, _vp],
     "mtn_debug_set": [_i, _i],
 }
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}

@@ -181,6 +181,29 @@ int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors, int max_elems,
                      int dtype, void* stream);
 
+/* ---- step metrics on the device (reference: host numpy / sklearn per step) ------
+ * get_max_preds (libs/utils.py:4-32): preds f32 [maps][2] = (x, y) of the first maximum, zeroed
+ * where the maximum is <= 0; maxvals f32 [maps] (optional).  maps = B*J. */
+int mtn_heatmap_argmax(const float* hm, float* preds, float* maxvals, int maps, int H, int W, void* stream);
+/* pose_accuracy (libs/metrics.py:31-62) from decoded coordinates: acc f32 [J+2] =
+ * (mean over valid joints, per-joint accuracy or -1 ..., number of valid joints). */
+int mtn_pose_accuracy(const float* pred_xy, const float* target_xy, float* acc, int B, int J, int H,
+                      int W, float thr, void* stream);
+/* argmax of the logits (train.py:66) and confusion counts cm[pred][label] += 1 (int32 [C][C],
+ * accumulated; either output may be NULL) */
+int mtn_cls_confusion(const float* logits, const long long* label, long long* pred_label, int* cm, int B,
+                      int C, void* stream);
+/* macro F1 over the labels present (sklearn f1_score(average='macro') as used at train.py:67-69) */
+int mtn_macro_f1(const int* cm, float* f1, int C, void* stream);
+
+/* ---- input side on the device ------------------------------------------------
+ * Gaussian heat-map targets of libs/load.py:148-206: joints f32 [maps][2] in image pixels,
+ * vis f32 [maps] -> target f32 [maps][HH][HW] (peak 1, (6*sigma+1)^2 patch), weight f32 [maps]. */
+int mtn_render_targets(const float* joints, const float* vis, float* target, float* weight, int maps,
+                       int HH, int HW, int img_h, int img_w, int sigma, void* stream);
+/* uint8 HWC image batch (cv2 order) -> fp32 NCHW, /255 then ImageNet mean/std (libs/load.py:46-50) */
+int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B, int H, int W, void* stream);
+
 /* test / tuning hook: key 1 = ds_read_b64_tr_b16 operand reads in wgrad (default 1);
  * key 3 = igemm pipeline (1: register-staged single LDS buffer; 2: register-staged double buffer;
  *         3: LDS-DMA double buffer (default); 4: LDS-DMA triple buffer with counted vmcnt) */
