@@ -60,20 +60,23 @@ def igemm_roofline(step, batch):
             return r
         return inner
 
+    def nbytes(*ts):
+        return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
     def g_fwd(x, w, y, stats, k, s):
         B, H, W, Cin = x.shape
         Cout, M = y.shape[-1], y.numel() // y.shape[-1]
-        return (2.0 * M * Cout * k * k * Cin) if big_tile(M, Cout) else None
+        return (2.0 * M * Cout * k * k * Cin, nbytes(x, w, y)) if big_tile(M, Cout) else None
 
     def g_dgrad(dy, wt, dx, res, k, s):
         Cout, Min = dy.shape[-1], dx.numel() // dx.shape[-1]
         Cin, Mout = dx.shape[-1], dy.numel() // dy.shape[-1]
-        return (2.0 * Mout * Cout * k * k * Cin) if big_tile(Min, Cin) else None
+        return (2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res)) if big_tile(Min, Cin) else None
 
-    def g_lin(x, w, out, **kw):
+    def g_lin(x, w, out, bias=None, act=0, aux_out=None, res=None):
         K, N = x.shape[-1], out.shape[-1]
         M = x.numel() // K
-        return (2.0 * M * N * K) if big_tile(M, N) else None
+        return (2.0 * M * N * K, nbytes(x, w, out, aux_out, res)) if big_tile(M, N) else None
 
     saved = (ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd)
     ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = (wrap("conv_fwd", saved[0], g_fwd), wrap("conv_dgrad", saved[1], g_dgrad),
@@ -83,13 +86,26 @@ def igemm_roofline(step, batch):
         torch.cuda.synchronize()
     finally:
         ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = saved
-    flops = sum(r[1] for r in rec)
+    flops = sum(r[1][0] for r in rec)
+    abytes = sum(r[1][1] for r in rec)
     secs = sum(r[2].elapsed_time(r[3]) for r in rec) * 1e-3
     achieved = flops / secs / 1e12
-    return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,128,128,2,2>", "achieved": round(achieved, 1),
-            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": None, "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
-            "flops_per_launch": flops / len(rec), "share_of_step_ms": round(secs * 1e3, 3)}
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes)
+    traffic, src = None, None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.startswith("r01_pmc_hbm_traffic") and name.endswith(".json"):
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            for k, v in pm.items():
+                if k.startswith("igemm_kernel<bf16_t, 128, 128"):
+                    traffic, src = round(v["hbm_bytes_per_dispatch"]), "profiles/" + name
+            break
+    return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,128,128,2,2,...> (67 launches/step: conv fwd + dgrad + ViT linears)",
+            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+            "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
+            "flops_per_launch": round(flops / len(rec)), "algorithmic_bytes_per_launch": round(abytes / len(rec)),
+            "share_of_step_ms": round(secs * 1e3, 3)}
 
 
 def cpu_baseline(size):

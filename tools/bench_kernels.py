@@ -81,6 +81,20 @@ def main():
         fl = 2.0 * M * Cout * k * k * Cin
         by = (x.numel() + dy.numel()) * esz
         print(f"conv_wgrad.{name:6s} M={M:8d} N={Cout:4d} K={k*k*Cin:5d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s  ws={wsb/1e6:.0f}MB")
+    if not a.filter or "bn" in a.filter:
+        for M, C in ((B * 96 * 96, 64), (B * 48 * 48, 128), (B * 48 * 48, 256), (B * 12 * 12, 512)):
+            y = torch.randn(M, C, device=dev).to(dt)
+            out = torch.empty_like(y)
+            ss = torch.randn(2, C, device=dev)
+            mr = torch.rand(2, C, device=dev) + 0.5
+            t = timeit(lambda: ops.bn_act_fwd(y, ss, out, ops.ACT_SILU))
+            print(f"bn_act_fwd M={M:8d} C={C:4d} {t*1e6:8.1f} us  {2*M*C*esz/t/1e9:7.0f} GB/s")
+            dout = torch.randn(M, C, device=dev).to(dt)
+            part = torch.empty(ops.bn_bwd_partial_rows(M), 2, C, device=dev)
+            coef, dg, db = torch.empty(2, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+            dy = torch.empty_like(y)
+            t = timeit(lambda: ops.bn_act_bwd(dout, y, None, ss, mr, part, coef, dg, db, dy, ops.ACT_SILU))
+            print(f"bn_act_bwd M={M:8d} C={C:4d} {t*1e6:8.1f} us  {5*M*C*esz/t/1e9:7.0f} GB/s (reduce 2 reads + apply 2 reads 1 write)")
     if not a.filter or "pose" in a.filter:
         from hand_gesture_recognition_amd import lib
         h = w = 12
