@@ -100,20 +100,36 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     // (oy&1, ox&1, b, oy/2, ox/2): a tile then holds pixels of ONE parity class, for which only
     // 1, 2 or 4 of the 9 taps can hit a stored gradient, and the K loop skips the others
     // (2.25 taps on average instead of 9).  Output rows are always written at the natural index.
+    // The first row of the tile is decoded once with real divisions (m0 is workgroup-uniform); a
+    // row r of the tile is then (x0 + r) carried into y and b with multiply-high "magic" divisions
+    // (exact for operands < 2^16, host-checked), which removes ~6 integer divisions per row from
+    // both the loader prologue and the epilogue.
+    const int dW_ = p.pm ? (p.OW >> 1) : p.OW, dH_ = p.pm ? (p.OH >> 1) : p.OH;
+    int q0, b0, y0, x0;
+    {
+        const int per = p.B * dH_ * dW_;
+        q0 = p.pm ? m0 / per : 0;
+        const int r = m0 - q0 * per;
+        b0 = r / (dH_ * dW_);
+        const int rr = r - b0 * dH_ * dW_;
+        y0 = rr / dW_;
+        x0 = rr - y0 * dW_;
+    }
     auto decode = [&](int m, int& b, int& oy, int& ox) {
+        const unsigned xt = (unsigned)(x0 + (m - m0));
+        const unsigned yi = dW_ == 1 ? xt : __umulhi(xt, p.magic_w);       // xt / dW_
+        const unsigned yt = (unsigned)y0 + yi;
+        const unsigned bi = dH_ == 1 ? yt : __umulhi(yt, p.magic_h);       // yt / dH_
+        int x = (int)(xt - yi * (unsigned)dW_), y = (int)(yt - bi * (unsigned)dH_);
+        b = b0 + (int)bi;
         if (p.pm) {
-            const int h2 = p.OH >> 1, w2 = p.OW >> 1, per = p.B * h2 * w2;
-            const int q = m / per, r = m - q * per;
-            b = r / (h2 * w2);
-            const int rr = r - b * h2 * w2, y2 = rr / w2;
-            oy = 2 * y2 + (q >> 1);
-            ox = 2 * (rr - y2 * w2) + (q & 1);
+            int q = q0;
+            while (b >= p.B) { b -= p.B; ++q; }        // a tile may straddle parity classes
+            oy = 2 * y + (q >> 1);
+            ox = 2 * x + (q & 1);
         } else {
-            const int ohw = p.OH * p.OW;
-            b = m / ohw;
-            const int rem = m - b * ohw;
-            oy = rem / p.OW;
-            ox = rem - oy * p.OW;
+            oy = y;
+            ox = x;
         }
     };
     // row/chunk owned by this thread in each of its RA (RB) loads.  Register staging: rows
@@ -399,6 +415,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     return mtn_check_launch("igemm");
 }
 
+static int g_tile_n64 = 128;     // rows per tile for 64-wide outputs (debug key 4)
 static int g_igemm_stages = 3;   // LDS-DMA double buffer (measured fastest: see DESIGN.md section 4)
 
 template <class T, int BM, int BN, int WGM, int WGN>
@@ -413,6 +430,7 @@ template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     if (p.N % 128 == 0 && p.M >= 128 * 64) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
     if (p.N % 128 == 0) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
+    if (g_tile_n64 == 256 && p.M >= 256 * 256) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
     return launch_igemm_mode<T, 128, 64, 4, 1>(p, stream);
 }
 
@@ -420,13 +438,22 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
 
 void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 4) ? n : 3; }
 
+void mtn_igemm_set_tile_n64(int rows) { g_tile_n64 = rows == 256 ? 256 : 128; }
+
 int mtn_igemm_tiles_m(int M, int N) {
     if (N % 128 == 0 && M >= 128 * 64) return mtn_cdiv(M, 128);
     if (N % 128 == 0) return mtn_cdiv(M, 64);
+    if (g_tile_n64 == 256 && M >= 256 * 256) return mtn_cdiv(M, 256);
     return mtn_cdiv(M, 128);
 }
 
-int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
+int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
+    IgemmArgs p = p0;
+    {   // magic = floor(2^32 / d) + 1: __umulhi(x, magic) == x / d for x * d < 2^32
+        const unsigned dw = (unsigned)(p.pm ? p.OW / 2 : p.OW), dh = (unsigned)(p.pm ? p.OH / 2 : p.OH);
+        p.magic_w = dw > 1 ? (unsigned)(0x100000000ull / dw) + 1u : 0u;
+        p.magic_h = dh > 1 ? (unsigned)(0x100000000ull / dh) + 1u : 0u;
+    }
     const int bk = dtype == MTN_BF16 ? 64 : 32;
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "igemm: bad dtype %d", dtype);
     MTN_REQUIRE(p.M > 0 && p.N > 0 && p.N % 64 == 0, "igemm: N=%d must be a positive multiple of 64 (M=%d)", p.N, p.M);
@@ -434,6 +461,7 @@ int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "igemm: K=%d != KH*KW*Cin", p.K);
     MTN_REQUIRE(p.div == 1 || p.div == 2, "igemm: div=%d", p.div);
     MTN_REQUIRE(p.KH * p.KW <= 9, "igemm: at most 9 taps");
+    MTN_REQUIRE(p.OH < 32768 && p.OW < 32768, "igemm: spatial size too large for the magic row decode");
     MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && !p.stats), "igemm: parity-major rows need even OH/OW");
     MTN_REQUIRE(p.lda % (bk / 8) == 0 && p.ldc % (bk / 8) == 0, "igemm: lda/ldc must keep 16-byte alignment");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "igemm: M=%d != B*OH*OW", p.M);

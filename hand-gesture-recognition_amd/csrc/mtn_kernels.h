@@ -24,6 +24,7 @@ struct IgemmArgs {
     int ldr;
     float* stats;         // [tiles_m][2][N] BN partial sums, or null
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
+    unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
 };
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
@@ -123,3 +124,4 @@ int mtn_macro_f1_run(const int* cm, float* f1, int C, hipStream_t stream);
 int mtn_render_targets_run(const float* joints, const float* vis, float* target, float* weight, int maps, int HH, int HW,
                            int img_h, int img_w, int sigma, hipStream_t stream);
 int mtn_normalize_image_run(const unsigned char* img, float* out, int B, int H, int W, hipStream_t stream);
+void mtn_igemm_set_tile_n64(int rows);

@@ -325,6 +325,7 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
 }
 
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 inline float atomicMax(float* p, float v) { float o = *p; if (v > o) *p = v; return o; }
 inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
