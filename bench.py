@@ -33,7 +33,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--size", type=int, default=192)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="replay the step from a hipGraph (measured equal to eager launch: the step is GPU-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()

@@ -1,7 +1,7 @@
 // conv1.hip -- the stem Conv(3, 64, k=3, s=2) of GELANNet (model/gelan.py:155) and its weight
-// gradient.  K = 27 is far too shallow for MFMA and the layer is HBM/issue bound (23 flop/B), so
-// it is a direct VALU convolution that reads the dataloader's NCHW fp32 image as is (no layout
-// pass over the input; libs/load.py:46-50 batch contract) and writes the NHWC activation the
+// gradient.  The layer is HBM bound (20 flop/B); both kernels gather the 27-tap patch straight
+// from the dataloader's NCHW fp32 image (no layout pass over the input; libs/load.py:46-50 batch
+// contract), pad K to 32 and run one-K-step MFMA GEMMs; the forward writes the NHWC activation the
 // rest of the backbone uses.  No data gradient: the image needs none.
 #include "mtn_types.h"
 #include "mtn_kernels.h"
@@ -106,57 +106,66 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
-// partial[block][co*27 + ci*9 + kh*3 + kw]  (already in the reference's OIHW order)
+// Weight gradient of the stem as a TN GEMM on MFMA: dW[co][k] = sum_px dY[px][co] * A[px][k], A = the
+// 27-tap im2col patch (padded to 32) gathered from the NCHW fp32 image like in the forward.
+// Per step a workgroup stages 64 pixels of dY ([px][64], 16-byte coalesced) and of A ([px][32]) in
+// LDS and reads both operands down the pixel axis (ds_read_b64_tr_b16 in bf16); wave w owns output
+// channels 16w..16w+15 x all 32 k.  partial[block][co*27 + ci*9 + kh*3 + kw] (reference OIHW order).
 constexpr int WPX = 64;        // pixels staged per step
-template <class T>
+template <class T, bool TR>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                           float* __restrict__ partial, int B, int H, int W, int OH,
                                                           int OW, int px_per_block) {
     constexpr int VEC = 16 / (int)sizeof(T);
-    __shared__ float sdy[WPX][CO];
-    __shared__ float sx[WPX][32];
-    const int tid = threadIdx.x;
-    const int cg = tid >> 5, k = tid & 31;       // 8 channel groups x 32 tap slots (27 used)
+    constexpr int KI = Mma<T>::KI;
+    constexpr int PY = CO + 16 / (int)sizeof(T), PA = 32 + 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) T sY[WPX * PY];
+    __shared__ __attribute__((aligned(16))) T sA[WPX * PA];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const long M = (long)B * OH * OW;
     const long m0 = (long)blockIdx.x * px_per_block;
     long m1 = m0 + px_per_block;
     if (m1 > M) m1 = M;
     const int ohw = OH * OW;
-    float acc[8];
-    MTN_UNROLL for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const int kh = k / 9, kw = (k / 3) % 3, ci = k % 3;    // k = (kh, kw, ci), ci fastest
+    f32x4_t acc0 = zero4(), acc1 = zero4();
     for (long mb = m0; mb < m1; mb += WPX) {
-        // stage dy rows: WPX x 64 values, 16-byte chunks
+        // dY rows: 64 px x 64 ch
         for (int i = tid; i < WPX * (CO / VEC); i += 256) {
             const int r = i / (CO / VEC), c = (i - r * (CO / VEC)) * VEC;
-            float v[VEC];
-            if (mb + r < m1) unpack<T>(*reinterpret_cast<const chunk16*>(dy + (mb + r) * CO + c), v);
-            else { MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = 0.f; }
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) sdy[r][c + e] = v[e];
+            *reinterpret_cast<chunk16*>(sY + r * PY + c) =
+                (mb + r < m1) ? *reinterpret_cast<const chunk16*>(dy + (mb + r) * CO + c) : zero_chunk();
         }
-        // stage the 27-tap input patch of each pixel
-        for (int i = tid; i < WPX * 32; i += 256) {
-            const int r = i >> 5, kk = i & 31;
-            float v = 0.f;
+        // im2col patch: thread -> (pixel tid/4, k = 8*(tid%4) .. +7)
+        {
+            const int r = tid >> 2, k0 = (tid & 3) * 8;
             const long m = mb + r;
-            if (kk < KK && m < m1) {
+            float v[8];
+            MTN_UNROLL for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (m < m1) {
                 const int b = (int)(m / ohw), rem = (int)(m - (long)b * ohw);
                 const int oy = rem / OW, ox = rem - oy * OW;
-                const int iy = 2 * oy - 1 + kk / 9, ix = 2 * ox - 1 + (kk / 3) % 3;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long)b * 3 + kk % 3) * H + iy) * W + ix];
+                MTN_UNROLL for (int e = 0; e < 8; ++e) {
+                    const int kk = k0 + e;
+                    const int iy = 2 * oy - 1 + kk / 9, ix = 2 * ox - 1 + (kk / 3) % 3;
+                    if (kk < KK && iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = x[(((long)b * 3 + kk % 3) * H + iy) * W + ix];
+                }
             }
-            sx[r][kk] = v;
+            MTN_UNROLL for (int c = 0; c < 8; c += VEC) *reinterpret_cast<chunk16*>(sA + r * PA + k0 + c) = pack<T>(v + c);
         }
         __syncthreads();
-        for (int r = 0; r < WPX; ++r) {
-            const float xv = sx[r][k];
-            MTN_UNROLL for (int e = 0; e < 8; ++e) acc[e] = fmaf(sdy[r][cg * 8 + e], xv, acc[e]);
+        MTN_UNROLL for (int ks = 0; ks < WPX / KI; ++ks) {
+            const typename Mma<T>::Frag fa = ColFrag<T, TR>::load(sY + ks * KI * PY + wid * 16, PY, lane);
+            acc0 = Mma<T>::mma(fa, ColFrag<T, TR>::load(sA + ks * KI * PA, PA, lane), acc0);
+            acc1 = Mma<T>::mma(fa, ColFrag<T, TR>::load(sA + ks * KI * PA + 16, PA, lane), acc1);
         }
         __syncthreads();
     }
-    if (k < KK) {
-        float* out = partial + (long)blockIdx.x * CO * KK;
-        MTN_UNROLL for (int e = 0; e < 8; ++e) out[(cg * 8 + e) * KK + ci * 9 + kh * 3 + kw] = acc[e];
+    float* out = partial + (long)blockIdx.x * CO * KK;
+    MTN_UNROLL for (int r = 0; r < 4; ++r) {
+        const int co = wid * 16 + 4 * (lane >> 4) + r;
+        const int k0 = lane & 15, k1 = 16 + (lane & 15);
+        out[co * KK + (k0 % 3) * 9 + (k0 / 9) * 3 + (k0 / 3) % 3] = acc0[r];
+        if (k1 < KK) out[co * KK + (k1 % 3) * 9 + (k1 / 9) * 3 + (k1 / 3) % 3] = acc1[r];
     }
 }
 
@@ -197,10 +206,10 @@ int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partia
     const long M = (long)B * OH * OW;
     const int blocks = mtn_conv1_wgrad_blocks(M);
     if (dtype == MTN_BF16)
-        MTN_LAUNCH(conv1_wgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, x, (const bf16_t*)dy, partial, B, H, W,
+        MTN_LAUNCH((conv1_wgrad_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, x, (const bf16_t*)dy, partial, B, H, W,
                    OH, OW, kWgradPx);
     else
-        MTN_LAUNCH(conv1_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, stream, x, (const float*)dy, partial, B, H, W, OH,
+        MTN_LAUNCH((conv1_wgrad_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, x, (const float*)dy, partial, B, H, W, OH,
                    OW, kWgradPx);
     int rc = mtn_check_launch("conv1_wgrad");
     if (rc) return rc;

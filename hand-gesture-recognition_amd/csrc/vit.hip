@@ -65,13 +65,16 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const T* __restrict__ d
         store_row4<T>(dfeat + r * DIM + lane * EPL, v);
     }
 }
-// dcls[c] = sum_b dtok[b][0][c]   (single block; B rows)
+// dcls[c] = sum_b dtok[b][0][c]   (one 1024-thread block: 4 batch lanes x 256 channels)
 template <class T>
-__global__ __launch_bounds__(256) void cls_grad_kernel(const T* __restrict__ dtok, float* __restrict__ dcls, int B, int P) {
-    const int c = threadIdx.x;
+__global__ __launch_bounds__(1024) void cls_grad_kernel(const T* __restrict__ dtok, float* __restrict__ dcls, int B, int P) {
+    __shared__ float red[4][DIM];
+    const int c = threadIdx.x & 255, bq = threadIdx.x >> 8;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += to_f<T>(dtok[(long)b * (P + 1) * DIM + c]);
-    dcls[c] = s;
+    for (int b = bq; b < B; b += 4) s += to_f<T>(dtok[(long)b * (P + 1) * DIM + c]);
+    red[bq][c] = s;
+    __syncthreads();
+    if (bq == 0) dcls[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
 // ---- LayerNorm -----------------------------------------------------------------------------------
@@ -234,20 +237,26 @@ __global__ __launch_bounds__(64) void cls_head_bwd_x_kernel(const float* __restr
     store_row4<T>(dtok + (long)b * tok_stride + lane * EPL, g);
 }
 
-// block c: dW[c][k] = sum_b dl[b][c]*xn[b][k], dbias[c] = sum_b dl[b][c]
-__global__ __launch_bounds__(256) void cls_head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ lg,
-                                                             const float* __restrict__ lb, const float* __restrict__ xhat,
-                                                             float* __restrict__ dW, float* __restrict__ dbias, int B, int C) {
-    const int k = threadIdx.x, c = blockIdx.x;
+// block c (1024 threads = 4 batch lanes x 256 features): dW[c][k] = sum_b dl[b][c]*xn[b][k], dbias[c] = sum_b dl[b][c]
+__global__ __launch_bounds__(1024) void cls_head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ lg,
+                                                              const float* __restrict__ lb, const float* __restrict__ xhat,
+                                                              float* __restrict__ dW, float* __restrict__ dbias, int B, int C) {
+    __shared__ float red[2][4][DIM];
+    const int k = threadIdx.x & 255, bq = threadIdx.x >> 8, c = blockIdx.x;
     const float gk = lg[k], bk = lb[k];
     float s = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = bq; b < B; b += 4) {
         const float dl = dlogits[(long)b * C + c];
         s += dl * (xhat[(long)b * DIM + k] * gk + bk);
         sb += dl;
     }
-    dW[c * DIM + k] = s;
-    if (k == 0) dbias[c] = sb;
+    red[0][bq][k] = s;
+    red[1][bq][k] = sb;
+    __syncthreads();
+    if (bq == 0) {
+        dW[c * DIM + k] = red[0][0][k] + red[0][1][k] + red[0][2][k] + red[0][3][k];
+        if (k == 0) dbias[c] = red[1][0][0] + red[1][1][0] + red[1][2][0] + red[1][3][0];
+    }
 }
 
 inline int row_grid(long rows) {
@@ -277,10 +286,10 @@ int mtn_tokens_bwd_run(const void* dtok, void* dfeat, float* dcls, int dtype, in
     MTN_REQUIRE(B > 0 && P > 0, "tokens_bwd: bad sizes");
     if (dtype == MTN_BF16) {
         MTN_LAUNCH(tokens_bwd_kernel<bf16_t>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const bf16_t*)dtok, (bf16_t*)dfeat, B, P);
-        MTN_LAUNCH(cls_grad_kernel<bf16_t>, dim3(1), dim3(256), 0, stream, (const bf16_t*)dtok, dcls, B, P);
+        MTN_LAUNCH(cls_grad_kernel<bf16_t>, dim3(1), dim3(1024), 0, stream, (const bf16_t*)dtok, dcls, B, P);
     } else {
         MTN_LAUNCH(tokens_bwd_kernel<float>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const float*)dtok, (float*)dfeat, B, P);
-        MTN_LAUNCH(cls_grad_kernel<float>, dim3(1), dim3(256), 0, stream, (const float*)dtok, dcls, B, P);
+        MTN_LAUNCH(cls_grad_kernel<float>, dim3(1), dim3(1024), 0, stream, (const float*)dtok, dcls, B, P);
     }
     return mtn_check_launch("tokens_bwd");
 }
@@ -358,7 +367,7 @@ int mtn_cls_head_bwd_run(const float* dlogits, const float* W, const float* lg, 
         MTN_LAUNCH(cls_head_bwd_x_kernel<bf16_t>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (bf16_t*)dtok, tok_stride, partial, C);
     else
         MTN_LAUNCH(cls_head_bwd_x_kernel<float>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (float*)dtok, tok_stride, partial, C);
-    MTN_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, stream, dlogits, lg, lb, xhat, dW, dbias, B, C);
+    MTN_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(1024), 0, stream, dlogits, lg, lb, xhat, dW, dbias, B, C);
     int rc = mtn_check_launch("cls_head_bwd");
     if (rc) return rc;
     return mtn_colsum_run(partial, B, 2 * DIM, dlg_dlb, stream);

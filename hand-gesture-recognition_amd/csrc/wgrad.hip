@@ -18,51 +18,6 @@ namespace {
 
 constexpr int PADB = 16;      // LDS row padding in bytes
 
-// operand fragment read down the reduction (row) axis of a [rows][pitch] LDS tile;
-// base points at [k0][col0]; lane gets rows k0 + koff.., column col0 + (lane & 15).
-template <class T, bool TR> struct ColFrag;
-template <bool TR> struct ColFrag<float, TR> {
-    static __device__ __forceinline__ float load(const float* base, int pitch, int lane) {
-        return base[(lane >> 4) * pitch + (lane & 15)];
-    }
-};
-template <> struct ColFrag<bf16_t, false> {
-    static __device__ __forceinline__ bf16x8_t load(const bf16_t* base, int pitch, int lane) {
-        bf16x8_t f;
-        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + (8 * (lane >> 4)) * pitch + (lane & 15);
-        unsigned short v[8];
-        MTN_UNROLL for (int j = 0; j < 8; ++j) v[j] = p[j * pitch];
-#ifdef MTN_EMU
-        MTN_UNROLL for (int j = 0; j < 8; ++j) f[j] = v[j];
-#else
-        MTN_UNROLL for (int j = 0; j < 8; ++j) f[j] = __builtin_bit_cast(__bf16, v[j]);
-#endif
-        return f;
-    }
-};
-template <> struct ColFrag<bf16_t, true> {
-    // two transposed 4x16 block reads: rows 8g..8g+3 and 8g+4..8g+7 (g = lane>>4); lane 4q+p of
-    // the group addresses row q, columns 4p..4p+3 and receives column (lane&15) of the 4 rows.
-    static __device__ __forceinline__ bf16x8_t load(const bf16_t* base, int pitch, int lane) {
-        const int g = lane >> 4, i = lane & 15;
-        const bf16_t* p0 = base + (8 * g + (i >> 2)) * pitch + 4 * (i & 3);
-        const bf16_t* p1 = p0 + 4 * pitch;
-        bf16x8_t f;
-#ifdef MTN_EMU
-        emu::u16x4 a = emu::ds_read_tr16_b64(p0), b = emu::ds_read_tr16_b64(p1);
-        MTN_UNROLL for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
-#else
-        // (the v4i16 form + per-element bit_cast is mis-lowered by hipcc 7.2: use v4bf16 + shuffle)
-        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
-        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p0));
-        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p1));
-        f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-#endif
-        return f;
-    }
-};
-
 template <class T, int BN, int BC, int WGM, int WGN, bool TR>
 __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     constexpr int NT = WGM * WGN * 64;

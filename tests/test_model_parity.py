@@ -180,3 +180,36 @@ def test_eval_mode_gpu(golden_dir):
     ref = O.multitasknet_forward(batch[0], {k: v.clone() for k, v in sd.items()}, training=False)
     assert rel_err(cls_out, ref[0]) < 1e-3 and rel_err(hmap, ref[1]) < 1e-3 and rel_err(attn, ref[2]) < 1e-3
     assert all(int(v) == 0 for k, v in model.state_dict().items() if k.endswith("num_batches_tracked"))
+
+
+def test_nonsquare_image_emu():
+    """The model (unlike the reference's train.py:191-192 assert) accepts H != W: 32x64 -> 2x4 tokens."""
+    be = Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=6)
+    model = MultiTaskNet(21, 19, [32, 64], compute_dtype=torch.float32)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 32, 64, generator=g)
+    cls_out, hmap, attn = model(x)
+    (cls_out.sum() * 0.1 + (hmap ** 2).mean()).backward()
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k in O.param_keys():
+        sdo[k].requires_grad_(True)
+    rc, rh, ra = O.multitasknet_forward(x, sdo, training=True)
+    (rc.sum() * 0.1 + (rh ** 2).mean()).backward()
+    assert hmap.shape == (2, 21, 8, 16) and attn.shape == (2, 8, 9, 9)
+    assert rel_err(cls_out, rc) < 1e-3 and rel_err(hmap, rh) < 1e-3 and rel_err(attn, ra) < 1e-3
+    worst = max((rel_err(p.grad, sdo[k].grad), k) for k, p in model.named_parameters())
+    assert worst[0] < 1e-3, worst
+
+
+@pytest.mark.gpu
+def test_train_cli_gpu():
+    """the reference's flag surface end to end: python -m hand_gesture_recognition_amd.train ..."""
+    from hand_gesture_recognition_amd import lib, train
+    lib.use_library(lib.HIP_LIB)
+    args = train.build_parser().parse_args(["--batch_size", "4", "--epochs", "2", "--steps_per_epoch", "2",
+                                            "--image_size", "64", "64", "--lr", "1e-3", "--lr_step", "1", "5"])
+    model = train.run(args, {"num_joints": 21, "num_classes": 19})
+    assert all(torch.isfinite(p).all() for p in model.parameters())
