@@ -3,7 +3,7 @@
 // A single-OS-thread, fiber-based executor for the HIP kernels under
 // hand-gesture-recognition_amd/csrc, so that their *logic* (indexing, LDS layouts, MFMA fragment
 // maps, barriers) can be exercised on the CPU-only build container at tiny sizes.  Every GPU
-// thread is a ucontext fiber; blocks run one after another; __syncthreads(), wave shuffles and
+// thread is a fiber (own stack + a ~10 ns register switch); blocks run one after another; __syncthreads(), wave shuffles and
 // MFMA are rendezvous points between the fibers of a block / a 64-lane wave.  Fibers are resumed
 // round-robin, so a missing barrier between an LDS write and a read shows up as wrong data.
 //
@@ -13,7 +13,6 @@
 // MFMA lane maps follow /opt/skills/guides/cdna_hip_programming.md section 3; they are
 // re-validated against the hardware by tests/test_mfma_layout.py (-m gpu).
 #pragma once
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -50,13 +49,26 @@ inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
 
 inline dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+// Minimal x86-64 context switch (callee-saved registers + stack pointer): ~10 ns, no syscalls
+// (swapcontext costs two rt_sigprocmask calls per switch and dominated the emulation time).
+extern "C" void mtn_emu_switch(void** save_sp, void* load_sp);
+asm(".text\n"
+    ".weak mtn_emu_switch\n"
+    ".type mtn_emu_switch,@function\n"
+    "mtn_emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n");
+
 namespace emu {
 
 constexpr int kStack = 96 * 1024;
 constexpr int kWave = 64;
 
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;
     bool done;
 };
 
@@ -68,7 +80,7 @@ struct Wave {
     alignas(16) unsigned char slot[2][kWave][64];
 };
 
-inline ucontext_t g_main;
+inline void* g_main_sp = nullptr;
 inline std::vector<Fiber> g_fibers;
 inline std::vector<Wave> g_waves;
 inline std::vector<char> g_stacks;
@@ -79,7 +91,7 @@ inline unsigned g_bar_gen = 0;
 inline unsigned long g_progress = 0;
 inline char* g_dyn_smem = nullptr;
 
-inline void yield() { swapcontext(&g_fibers[g_cur].ctx, &g_main); }
+inline void yield() { mtn_emu_switch(&g_fibers[g_cur].sp, g_main_sp); }
 inline int lane() { return g_cur & (kWave - 1); }
 inline Wave& wave() { return g_waves[g_cur / kWave]; }
 
@@ -107,7 +119,8 @@ inline void trampoline() {
     ++g_progress;
     barrier_release_if_complete();   // threads that returned no longer take part
     wave_release_if_complete(w);
-    swapcontext(&g_fibers[g_cur].ctx, &g_main);
+    mtn_emu_switch(&g_fibers[g_cur].sp, g_main_sp);
+    std::abort();                    // a finished fiber is never resumed
 }
 
 // Rendezvous of the live lanes of the calling fiber's wave.  Returns the slot parity used.
@@ -150,11 +163,14 @@ inline void launch(dim3 grid, dim3 block, size_t smem, F body) {
         for (int i = 0; i < n; ++i) {
             Fiber& f = g_fibers[i];
             f.done = false;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = g_stacks.data() + (size_t)i * kStack;
-            f.ctx.uc_stack.ss_size = kStack;
-            f.ctx.uc_link = &g_main;
-            makecontext(&f.ctx, (void (*)())trampoline, 0);
+            // initial frame: six zeroed callee-saved registers, then the entry point as return address;
+            // 16-byte aligned so that the entry sees the ABI's (rsp % 16 == 8) after the `ret`
+            uintptr_t top = ((uintptr_t)(g_stacks.data() + (size_t)(i + 1) * kStack) & ~(uintptr_t)15) - 64;
+            void** sp = reinterpret_cast<void**>(top);
+            for (int q = 0; q < 6; ++q) sp[q] = nullptr;
+            sp[6] = reinterpret_cast<void*>(&trampoline);
+            sp[7] = nullptr;
+            f.sp = sp;
         }
         unsigned long stalled_rounds = 0;
         while (g_alive > 0) {
@@ -163,7 +179,7 @@ inline void launch(dim3 grid, dim3 block, size_t smem, F body) {
                 if (g_fibers[i].done) continue;
                 g_cur = i;
                 threadIdx = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-                swapcontext(&g_main, &g_fibers[i].ctx);
+                mtn_emu_switch(&g_main_sp, g_fibers[i].sp);
             }
             if (g_progress == before) {
                 if (++stalled_rounds > 4) {
