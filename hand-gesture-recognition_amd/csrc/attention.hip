@@ -133,7 +133,7 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, f32x4_t 
 
 // ---- forward ------------------------------------------------------------------------------------
 template <class T, int MAXT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
                                                        float* __restrict__ attn, int N, int H, float scale) {
     constexpr int PITCH = Lay<T>::PITCH;
     MTN_DYN_SMEM(smem);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     stage_head<T>(sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    for (int qt = wid; qt < nqt; qt += 4) {
+    for (int qt = wid; qt < nqt; qt += (int)(blockDim.x >> 6)) {
         const int q = qt * 16 + li;
         const bool qok = q < N;
         RowOp<T> qf;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 
 // ---- backward 1: dQ (sums over keys) and delta = rowsum(dO * O) ----------------------------------
 template <class T, int MAXT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, T* __restrict__ dqkv, int N, int H,
                                                           float scale) {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     stage_head<T>(sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    for (int qt = wid; qt < nqt; qt += 4) {
+    for (int qt = wid; qt < nqt; qt += (int)(blockDim.x >> 6)) {
         const int q = qt * 16 + li;
         const bool qok = q < N;
         const long qr = row0 + (qok ? q : 0);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 
 // ---- backward 2: dK, dV (sum over queries); LDS holds Q and dO of the head ------------------------
 template <class T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            T* __restrict__ dqkv, int N, int H, float scale) {
     constexpr int PITCH = Lay<T>::PITCH;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         }
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    for (int kt = wid; kt < nkt; kt += 4) {
+    for (int kt = wid; kt < nkt; kt += (int)(blockDim.x >> 6)) {
         const int key = kt * 16 + li;
         const bool kok = key < N;
         const long kr = row0 + (kok ? key : 0);
@@ -346,7 +346,7 @@ template <class T>
 int attn_fwd_t(const AttnArgs& a, hipStream_t stream) {
     const int NP = (a.N + 31) & ~31;
     const size_t lds = 2 * (size_t)NP * Lay<T>::PITCH * sizeof(T);
-    const dim3 grid(a.B * a.H), block(256);
+    const dim3 grid(a.B * a.H), block(NP / 16 <= 10 ? 256 : 512);   // long sequences: 1 WG/CU -> 8 waves
     if (NP / 16 <= 10) {
         set_max_lds(attn_fwd_kernel<T, 10>, lds);
         MTN_LAUNCH((attn_fwd_kernel<T, 10>), grid, block, lds, stream, (const T*)a.qkv, (T*)a.out, a.lse, a.attn, a.N, a.H, a.scale);
@@ -361,7 +361,7 @@ template <class T>
 int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
     const int NP = (a.N + 31) & ~31;
     const size_t lds = 2 * (size_t)NP * Lay<T>::PITCH * sizeof(T);
-    const dim3 grid(a.B * a.H), block(256);
+    const dim3 grid(a.B * a.H), block(NP / 16 <= 10 ? 256 : 512);
     if (NP / 16 <= 10) {
         set_max_lds(attn_bwd_dq_kernel<T, 10>, lds);
         MTN_LAUNCH((attn_bwd_dq_kernel<T, 10>), grid, block, lds, stream, (const T*)a.qkv, (const T*)a.out, (const T*)a.dout,
