@@ -52,6 +52,36 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
 // STAGES = 3: LDS-DMA (global_load_lds 16 B) into two unpadded, XOR-swizzled LDS buffers: the
 //             swizzle is applied to the per-lane SOURCE chunk and to the fragment read, the LDS
 //             image itself is lane-linear (rule 21).  One barrier per K step, no staging VGPRs.
+// LDS-DMA through a buffer descriptor: lane l copies 16 bytes from base + voff (32-bit byte offset)
+// to lds_block + 16*l; an offset beyond num_bytes is out of range and DELIVERS ZEROS, which is how
+// the zero padding of the convolution (and the tap-invalid rows of a strided data gradient) is
+// produced without a branch or 64-bit address arithmetic.
+struct BufDesc {
+#ifdef MTN_EMU
+    const char* base; unsigned bytes;
+#else
+    __amdgpu_buffer_rsrc_t rsrc;
+#endif
+};
+__device__ __forceinline__ BufDesc make_buf(const void* base, unsigned bytes) {
+    BufDesc d;
+#ifdef MTN_EMU
+    d.base = static_cast<const char*>(base); d.bytes = bytes;
+#else
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+#endif
+    return d;
+}
+__device__ __forceinline__ void buf_glds16(const BufDesc& d, unsigned voff, void* lds_block) {
+#ifdef MTN_EMU
+    char* dst = static_cast<char*>(lds_block) + 16 * (threadIdx.x & 63);
+    if ((unsigned long long)voff + 16 <= d.bytes) std::memcpy(dst, d.base + voff, 16);
+    else std::memset(dst, 0, 16);
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc, (__attribute__((address_space(3))) void*)lds_block, 16, (int)voff, 0, 0, 0);
+#endif
+}
+
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
@@ -142,6 +172,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     const int rstep_b = DMA ? 8 : RSTEP;
     const int dshift = p.div >> 1, dmask = p.div - 1;     // div in {1,2}
     int a_y[RA], a_x[RA], a_base[RA];
+    unsigned a_vy[RA], a_vx[RA];                           // per row: bit kh / kw set iff that tap row / column reads a stored pixel
     unsigned my_taps = 0;
     MTN_UNROLL for (int i = 0; i < RA; ++i) {
         const int m = m0 + row0 + i * rstep_a;
@@ -151,14 +182,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             a_y[i] = oy * p.mul + p.off;
             a_x[i] = ox * p.mul + p.off;
             a_base[i] = b * p.H * p.W;
-            if (p.pm)
-            for (int t = 0; t < p.KH * p.KW; ++t) {
-                const int ty = a_y[i] + (t / p.KW) * p.sgn, tx = a_x[i] + (t % p.KW) * p.sgn;
-                if (ty >= 0 && tx >= 0 && (ty & dmask) == 0 && (tx & dmask) == 0 && (ty >> dshift) < p.H && (tx >> dshift) < p.W)
-                    my_taps |= 1u << t;
+            // validity is separable: tap (kh, kw) is readable iff its row kh and its column kw are
+            unsigned vy = 0, vx = 0;
+            for (int t = 0; t < p.KH; ++t) {
+                const int ty = a_y[i] + t * p.sgn;
+                if (ty >= 0 && (ty & dmask) == 0 && (ty >> dshift) < p.H) vy |= 1u << t;
             }
+            for (int t = 0; t < p.KW; ++t) {
+                const int tx = a_x[i] + t * p.sgn;
+                if (tx >= 0 && (tx & dmask) == 0 && (tx >> dshift) < p.W) vx |= 1u << t;
+            }
+            a_vy[i] = vy; a_vx[i] = vx;
+            if (p.pm)
+                for (int t = 0; t < p.KH * p.KW; ++t)
+                    if (((vy >> (t / p.KW)) & (vx >> (t % p.KW))) & 1u) my_taps |= 1u << t;
         } else {
-            a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0;
+            a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0; a_vy[i] = 0; a_vx[i] = 0;
         }
     }
     // taps that touch at least one row of this tile (workgroup-wide OR through LDS); only the
@@ -203,6 +242,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
         }
     };
     // LDS-DMA issue of K step kt into buffer `stage` (no registers, no LDS stores)
+    const BufDesc bufA = make_buf(p.A, p.a_bytes), bufW = make_buf(p.Wp, p.w_bytes);
     auto dma_tiles = [&](int kt, int stage) {
         const int ti = kt / spt, c0 = (kt - ti * spt) * BK;
         const int tap = (int)((tap_list >> (4 * ti)) & 15ull);
@@ -210,17 +250,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         char* a = reinterpret_cast<char*>(sA + stage * BM * PITCH_E);
         char* b = reinterpret_cast<char*>(sB + stage * BN * PITCH_E);
+        const int cc = c0 + chunk * VEC;
         MTN_UNROLL for (int i = 0; i < RA; ++i) {
-            const int ty = a_y[i] + kh * p.sgn, tx = a_x[i] + kw * p.sgn;
-            const int iy = ty >> dshift, ix = tx >> dshift;
-            const bool ok = (ty >= 0) && (tx >= 0) && ((ty & dmask) == 0) && ((tx & dmask) == 0) &&
-                            (iy < p.H) && (ix < p.W);
-            const void* src = ok ? static_cast<const void*>(gA + (long)(a_base[i] + iy * p.W + ix) * p.lda + c0 + chunk * VEC)
-                                 : static_cast<const void*>(g_zero_page);
-            glds16(src, a + (wid * RA + i) * 1024);
+            const int iy = (a_y[i] + kh * p.sgn) >> dshift, ix = (a_x[i] + kw * p.sgn) >> dshift;
+            const unsigned e = (unsigned)((a_base[i] + iy * p.W + ix) * p.lda + cc) * (unsigned)sizeof(T);
+            buf_glds16(bufA, (((a_vy[i] >> kh) & (a_vx[i] >> kw)) & 1u) ? e : 0xFFFFFFF0u, a + (wid * RA + i) * 1024);
         }
         MTN_UNROLL for (int i = 0; i < RB; ++i)
-            glds16(gW + (long)(n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC, b + (wid * RB + i) * 1024);
+            buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
+                       b + (wid * RB + i) * 1024);
     };
     auto store_tiles = [&](int stage) {
         T* a = sA + stage * BM * PITCH;
@@ -451,6 +489,9 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     IgemmArgs p = p0;
     {   // magic = floor(2^32 / d) + 1: __umulhi(x, magic) == x / d for x * d < 2^32
         const unsigned dw = (unsigned)(p.pm ? p.OW / 2 : p.OW), dh = (unsigned)(p.pm ? p.OH / 2 : p.OH);
+        const size_t esz = dtype == MTN_BF16 ? 2 : 4;
+        p.a_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.lda + p.Cin) * esz);     // extent of the gather source
+        p.w_bytes = (unsigned)((size_t)p.N * p.K * esz);
         p.magic_w = dw > 1 ? (unsigned)(0x100000000ull / dw) + 1u : 0u;
         p.magic_h = dh > 1 ? (unsigned)(0x100000000ull / dh) + 1u : 0u;
     }
@@ -465,7 +506,8 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && !p.stats), "igemm: parity-major rows need even OH/OW");
     MTN_REQUIRE(p.lda % (bk / 8) == 0 && p.ldc % (bk / 8) == 0, "igemm: lda/ldc must keep 16-byte alignment");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "igemm: M=%d != B*OH*OW", p.M);
-    MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 31) && (long)p.M * p.ldc < (1L << 31), "igemm: tensor too large for 32-bit offsets");
+    MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 30) && (long)p.M * p.ldc < (1L << 31) && (long)p.N * p.K < (1L << 30),
+                "igemm: tensor too large for 32-bit byte offsets");
     MTN_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.Wp | (uintptr_t)p.Out | (uintptr_t)p.res | (uintptr_t)p.aux_out) % 16 == 0, "igemm: pointers must be 16-byte aligned");
     return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);
 }

@@ -25,6 +25,7 @@ struct IgemmArgs {
     float* stats;         // [tiles_m][2][N] BN partial sums, or null
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
+    unsigned a_bytes, w_bytes;   // filled by mtn_igemm_run: byte extents of A / Wp (buffer descriptors)
 };
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
