@@ -263,6 +263,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 2) { mtn_pose_set_dbg(value); return MTN_OK; }
     if (key == 3) { mtn_igemm_set_stages(value); return MTN_OK; }
     if (key == 4) { mtn_igemm_set_tile_n64(value); return MTN_OK; }
+    if (key == 5) { mtn_wgrad_set_dma(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

@@ -52,36 +52,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
 // STAGES = 3: LDS-DMA (global_load_lds 16 B) into two unpadded, XOR-swizzled LDS buffers: the
 //             swizzle is applied to the per-lane SOURCE chunk and to the fragment read, the LDS
 //             image itself is lane-linear (rule 21).  One barrier per K step, no staging VGPRs.
-// LDS-DMA through a buffer descriptor: lane l copies 16 bytes from base + voff (32-bit byte offset)
-// to lds_block + 16*l; an offset beyond num_bytes is out of range and DELIVERS ZEROS, which is how
-// the zero padding of the convolution (and the tap-invalid rows of a strided data gradient) is
-// produced without a branch or 64-bit address arithmetic.
-struct BufDesc {
-#ifdef MTN_EMU
-    const char* base; unsigned bytes;
-#else
-    __amdgpu_buffer_rsrc_t rsrc;
-#endif
-};
-__device__ __forceinline__ BufDesc make_buf(const void* base, unsigned bytes) {
-    BufDesc d;
-#ifdef MTN_EMU
-    d.base = static_cast<const char*>(base); d.bytes = bytes;
-#else
-    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-#endif
-    return d;
-}
-__device__ __forceinline__ void buf_glds16(const BufDesc& d, unsigned voff, void* lds_block) {
-#ifdef MTN_EMU
-    char* dst = static_cast<char*>(lds_block) + 16 * (threadIdx.x & 63);
-    if ((unsigned long long)voff + 16 <= d.bytes) std::memcpy(dst, d.base + voff, 16);
-    else std::memset(dst, 0, 16);
-#else
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc, (__attribute__((address_space(3))) void*)lds_block, 16, (int)voff, 0, 0, 0);
-#endif
-}
-
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;

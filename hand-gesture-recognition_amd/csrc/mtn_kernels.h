@@ -39,6 +39,7 @@ struct WgradArgs {
     int B, H, W, Cin, OH, OW, KH, KW, stride, pad;
     int M, N, K;
     int splits, rows_per_split;
+    unsigned y_bytes, x_bytes;    // filled by mtn_wgrad_run: byte extents of dY / X (buffer descriptors)
 };
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);
@@ -126,3 +127,4 @@ int mtn_render_targets_run(const float* joints, const float* vis, float* target,
                            int img_h, int img_w, int sigma, hipStream_t stream);
 int mtn_normalize_image_run(const unsigned char* img, float* out, int B, int H, int W, hipStream_t stream);
 void mtn_igemm_set_tile_n64(int rows);
+void mtn_wgrad_set_dma(int on);

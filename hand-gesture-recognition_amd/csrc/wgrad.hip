@@ -14,6 +14,8 @@
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
+static int g_wgrad_dma = 1;      // LDS-DMA pipeline (debug key 5 selects the register-staged one)
+
 namespace {
 
 constexpr int PADB = 16;      // LDS row padding in bytes
@@ -141,6 +143,166 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
             }
 }
 
+// ---- LDS-DMA variant ------------------------------------------------------------------------------
+// Same tiling, but the dY / X tiles go global -> LDS by buffer_load ... lds (16 B per lane, no
+// staging VGPRs, no ds_write; out-of-range offsets deliver the zero padding) into two buffers.
+// The LDS image is lane-linear, so the bank-conflict fix of the column (ds_read_b64_tr_b16) reads
+// is an XOR of the 32-byte unit index applied to the lane's SOURCE chunk and to the read address
+// (cdna_hip_programming.md rule 21): a half-wave's tr read touches rows {r..r+3, r+8..r+11} at one
+// unit column, and f2(row) sends those 8 rows to 8 different bank ranges.
+template <class T, int ROWE> struct Swz {
+    static constexpr int EPU = 32 / (int)sizeof(T);              // elements per 32-byte unit
+    static constexpr int ROWB = ROWE * (int)sizeof(T);
+    static constexpr int UNITS = ROWB / 32;
+    static_assert(ROWB == 128 || ROWB % 256 == 0, "row bytes");
+    static __device__ __forceinline__ int f2(int row) {
+        return ROWB == 128 ? (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) : ((row & 3) | (((row >> 3) & 1) << 2));
+    }
+    static __device__ __forceinline__ int off(int row, int col) {
+        const int unit = col / EPU;
+        return row * ROWE + ((unit ^ f2(row)) * EPU) + (col - unit * EPU);
+    }
+    static __device__ __forceinline__ int fetch_chunk(int row, int pos) { return (((pos >> 1) ^ f2(row)) << 1) | (pos & 1); }
+};
+
+// operand fragment read down the rows of a swizzled tile: rows k0.., column col0 + (lane & 15)
+template <class T, int ROWE> struct ColFragS;
+template <int ROWE> struct ColFragS<float, ROWE> {
+    static __device__ __forceinline__ float load(const float* tile, int k0, int col0, int lane) {
+        return tile[Swz<float, ROWE>::off(k0 + (lane >> 4), col0 + (lane & 15))];
+    }
+};
+template <int ROWE> struct ColFragS<bf16_t, ROWE> {
+    static __device__ __forceinline__ bf16x8_t load(const bf16_t* tile, int k0, int col0, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        const int r0 = k0 + 8 * g + (i >> 2), c = col0 + 4 * (i & 3);
+        const bf16_t* p0 = tile + Swz<bf16_t, ROWE>::off(r0, c);
+        const bf16_t* p1 = tile + Swz<bf16_t, ROWE>::off(r0 + 4, c);
+        bf16x8_t f;
+#ifdef MTN_EMU
+        emu::u16x4 a = emu::ds_read_tr16_b64(p0), b = emu::ds_read_tr16_b64(p1);
+        MTN_UNROLL for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+#else
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
+        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p0));
+        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p1));
+        f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+        return f;
+    }
+};
+
+template <class T, int BN, int BC, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BMR = 128 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
+    constexpr int CPRY = BN / VEC, CPRX = BC / VEC;                 // 16-byte slots per row
+    constexpr int RPBY = 64 / CPRY, RPBX = 64 / CPRX;               // rows per 1 KiB DMA block
+    constexpr int IY = BMR / RPBY / NW, IX = BMR / RPBX / NW;       // DMA instructions per wave per step
+    constexpr int WM = BN / WGM, WN = BC / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    static_assert(BMR % (RPBY * NW) == 0 && BMR % (RPBX * NW) == 0, "DMA mapping");
+
+    MTN_DYN_SMEM(smem);
+    T* const sY = reinterpret_cast<T*>(smem);          // [2][BMR][BN]
+    T* const sX = sY + 2 * BMR * BN;                   // [2][BMR][BC]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+
+    const int tiles_n = p.N / BN;
+    const int tiles = tiles_n * (p.K / BC);
+    int tile, split;
+    {
+        const int L = blockIdx.x;
+        if (p.splits % 8 == 0 && tiles <= 24) {
+            const int xcd = L & 7, j = L >> 3;
+            split = (j / tiles) * 8 + xcd;
+            tile = j % tiles;
+        } else {
+            split = L / tiles;
+            tile = L % tiles;
+        }
+    }
+    const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
+    const int n0 = tile_n * BN;
+    const int kcol0 = tile_k * BC;
+    const int tap = kcol0 / p.Cin, c0 = kcol0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const long m_begin = (long)split * p.rows_per_split;
+    long m_end = m_begin + p.rows_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int steps = (int)((m_end - m_begin + BMR - 1) / BMR);
+    const int ohw = p.OH * p.OW;
+
+    const BufDesc bufY = make_buf(p.dY, p.y_bytes), bufX = make_buf(p.X, p.x_bytes);
+    // this lane's row / source chunk in each of its DMA instructions
+    int yrow[IY], ychunk[IY];
+    MTN_UNROLL for (int i = 0; i < IY; ++i) {
+        yrow[i] = (wid * IY + i) * RPBY + lane / CPRY;
+        ychunk[i] = Swz<T, BN>::fetch_chunk(yrow[i], lane % CPRY);
+    }
+    int xrow[IX], xchunk[IX], xb[IX], xrem[IX];
+    MTN_UNROLL for (int i = 0; i < IX; ++i) {
+        xrow[i] = (wid * IX + i) * RPBX + lane / CPRX;
+        xchunk[i] = Swz<T, BC>::fetch_chunk(xrow[i], lane % CPRX);
+        const long m = m_begin + xrow[i];
+        xb[i] = (int)(m / ohw);
+        xrem[i] = (int)(m - (long)xb[i] * ohw);
+    }
+    auto dma_tiles = [&](int st, int stage) {
+        const long mb = m_begin + (long)st * BMR;
+        char* y = reinterpret_cast<char*>(sY + stage * BMR * BN);
+        char* x = reinterpret_cast<char*>(sX + stage * BMR * BC);
+        MTN_UNROLL for (int i = 0; i < IY; ++i) {
+            const long m = mb + yrow[i];
+            const unsigned off = (unsigned)(m * p.lddy + n0 + ychunk[i] * VEC) * (unsigned)sizeof(T);
+            buf_glds16(bufY, m < m_end ? off : 0xFFFFFFF0u, y + (wid * IY + i) * 1024);
+        }
+        MTN_UNROLL for (int i = 0; i < IX; ++i) {
+            const long m = mb + xrow[i];
+            const int oy = xrem[i] / p.OW, ox = xrem[i] - oy * p.OW;
+            const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+            const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned off = (unsigned)(((xb[i] * p.H + iy) * p.W + ix) * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
+            buf_glds16(bufX, ok ? off : 0xFFFFFFF0u, x + (wid * IX + i) * 1024);
+            xrem[i] += BMR;
+            while (xrem[i] >= ohw) { xrem[i] -= ohw; ++xb[i]; }
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
+
+    if (steps > 0) dma_tiles(0, 0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < steps) dma_tiles(st + 1, cur ^ 1);
+        const T* y = sY + cur * BMR * BN;
+        const T* x = sX + cur * BMR * BC;
+        MTN_UNROLL for (int ks = 0; ks < BMR / KI; ++ks) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFragS<T, BN>::load(y, ks * KI, wm * WM + i * 16, lane);
+            MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = ColFragS<T, BC>::load(x, ks * KI, wn * WN + j * 16, lane);
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = p.partial + (long)split * p.N * p.K;
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j)
+            MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * WM + i * 16 + 4 * (lane >> 4) + r;
+                const int k = kcol0 + wn * WN + j * 16 + (lane & 15);
+                out[(long)n * p.K + k] = acc[i][j][r];
+            }
+}
+
 // dW_oihw[o][ci][kh][kw] = sum_s partial[s][o][(kh*KW+kw)*Cin + ci]; block = 4 split lanes x 64 elements
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int splits, int N, int K, int Cin, int taps) {
@@ -178,9 +340,28 @@ int launch_wgrad(const WgradArgs& p, hipStream_t stream) {
     return mtn_check_launch("wgrad");
 }
 
+template <class T, int BN, int BC, int WGM, int WGN>
+int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int BMR = 128 / (int)sizeof(T);
+    constexpr size_t lds = 2 * (size_t)BMR * (BN + BC) * sizeof(T);
+#ifndef MTN_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BN, BC, WGM, WGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+#endif
+    const int tiles = (p.N / BN) * (p.K / BC);
+    MTN_LAUNCH((wgrad_dma_kernel<T, BN, BC, WGM, WGN>), dim3(tiles * p.splits), dim3(NT), lds, stream, p);
+    return mtn_check_launch("wgrad_dma");
+}
+
 }  // namespace
 
 static int g_use_tr16 = 1;
+void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
 
 // tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
@@ -190,28 +371,38 @@ static void wgrad_tile(int N, int Cin, int* bn, int* bc) {
     if (*bn == 64 && *bc == 128) *bc = 64;          // (64,128) is not instantiated
 }
 
-// pixels per split: multiple of the step size, >= ~4096 rows, but enough splits to fill the chip
+// Split of the pixel axis: the launch should fill the chip's workgroup slots exactly once
+// (slots = 256 CUs x workgroups per CU at this tile's LDS footprint): one block more than a full
+// wave of workgroups costs a whole extra round, and every split adds a partial slab to reduce.
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split) {
     const int bmr = dtype == MTN_BF16 ? 64 : 32;
     int bn, bc;
     wgrad_tile(N, Cin, &bn, &bc);
     const long tiles = (long)(N / bn) * (K / bc);
-    long want = (M + 4095) / 4096;
-    const long fill = (512 + tiles - 1) / tiles;
-    if (want < fill) want = fill;
-    long rps = (M + want - 1) / want;
+    long slots = 1024;
+    if (g_wgrad_dma) slots = (bn == 128 && bc == 128) ? 512 : (bn == 128 ? 768 : 1024);
+    long splits = slots / tiles;
+    if (splits < 1) splits = 1;
+    if (splits >= 8 && tiles <= 24) splits &= ~7L;        // whole splits per XCD group (see the kernel)
+    const long max_splits = (M + bmr - 1) / bmr;
+    if (splits > max_splits) splits = max_splits;
+    long rps = (M + splits - 1) / splits;
     rps = (rps + bmr - 1) / bmr * bmr;
-    if (rps < bmr) rps = bmr;
     *rows_per_split = (int)rps;
-    long splits = (M + rps - 1) / rps;
-    if (splits >= 8) splits = (splits + 7) / 8 * 8;        // whole splits per XCD group (empty ones add zeros)
-    return (int)splits;
+    long n = (M + rps - 1) / rps;
+    if (n >= 8 && tiles <= 24) n = (n + 7) / 8 * 8;        // empty splits add zero slabs
+    return (int)n;
 }
 
 template <class T, bool TR>
 static int wgrad_dispatch(const WgradArgs& p, hipStream_t stream) {
     int bn, bc;
     wgrad_tile(p.N, p.Cin, &bn, &bc);
+    if (g_wgrad_dma && (TR || sizeof(T) == 4)) {
+        if (bn == 128 && bc == 128) return launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream);
+        if (bn == 128) return launch_wgrad_dma<T, 128, 64, 4, 1>(p, stream);
+        return launch_wgrad_dma<T, 64, 64, 2, 2>(p, stream);
+    }
     if (bn == 128 && bc == 128) return launch_wgrad<T, 128, 128, 2, 2, TR>(p, stream);
     if (bn == 128) return launch_wgrad<T, 128, 64, 4, 1, TR>(p, stream);
     return launch_wgrad<T, 64, 64, 2, 2, TR>(p, stream);
@@ -227,6 +418,12 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M,
                 "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
+    MTN_REQUIRE((long)p.M * p.lddy < (1L << 30) && (long)p.B * p.H * p.W * p.ldx < (1L << 30), "wgrad: tensor too large for 32-bit byte offsets");
+    {
+        const size_t esz = dtype == MTN_BF16 ? 2 : 4;
+        p.y_bytes = (unsigned)((((size_t)p.M - 1) * p.lddy + p.N) * esz);
+        p.x_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.ldx + p.Cin) * esz);
+    }
     int rc;
     if (dtype == MTN_BF16) rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
     else rc = wgrad_dispatch<float, false>(p, stream);

@@ -115,7 +115,7 @@ def test_linear_bias_gelu_residual(be, stages, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tr16", [0, 1])
+@pytest.mark.parametrize("tr16", [0, 1, 2])       # 0: scalar column reads, 1: ds_read_tr16 (register staged), 2: LDS-DMA (default)
 @pytest.mark.parametrize("cfg", [
     (2, 6, 6, 64, 64, 3, 1),
     (1, 8, 8, 64, 128, 3, 2),
@@ -127,13 +127,14 @@ def test_conv_wgrad(be, dtype, tr16, cfg):
     from hand_gesture_recognition_amd import lib
     if dtype == torch.float32 and tr16 == 0:
         pytest.skip("tr16 only affects bf16")
+    lib.call("mtn_debug_set", 5, 1 if tr16 == 2 else 0)
     B, H, W, Cin, Cout, k, s = cfg
     x = _rand((B, H, W, Cin), dtype, 12)
     w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
     yref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, k // 2)
     dy = _rand(tuple(yref.permute(0, 2, 3, 1).shape), dtype, 13)
     yref.backward(dy.float().permute(0, 3, 1, 2))
-    lib.call("mtn_debug_set", 1, tr16)
+    lib.call("mtn_debug_set", 1, min(tr16, 1))
     try:
         ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, k, s) // 4,
                          dtype=torch.float32, device=be.device)
@@ -142,6 +143,7 @@ def test_conv_wgrad(be, dtype, tr16, cfg):
         be.sync()
     finally:
         lib.call("mtn_debug_set", 1, 1)
+        lib.call("mtn_debug_set", 5, 1)
     assert rel_err(dw, w.grad) < tol(dtype, 1e-4, 1e-2)
 
 

@@ -33,11 +33,13 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--stages", type=int, default=3)
     ap.add_argument("--n64rows", type=int, default=128)
+    ap.add_argument("--wgrad_dma", type=int, default=1)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from hand_gesture_recognition_amd import lib as _lib
     _lib.call("mtn_debug_set", 3, a.stages)
     _lib.call("mtn_debug_set", 4, a.n64rows)
+    _lib.call("mtn_debug_set", 5, a.wgrad_dma)
     dev = torch.device("cuda:0")
     B = a.batch
     esz = 2 if dt == torch.bfloat16 else 4
