@@ -111,12 +111,14 @@ int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, 
 }
 
 size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K) {
-    return mtn_conv_wgrad_workspace_bytes(dtype, M, 1, 1, K, N, 1, 1);
+    return mtn_conv_wgrad_workspace_bytes(dtype, 1, 1, M, K, N, 1, 1);
 }
 
 int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                      size_t ws_bytes, int dtype, int M, int N, int K, void* stream) {
-    return mtn_conv_wgrad(x, ldx, dy, lddy, dw, workspace, ws_bytes, dtype, M, 1, 1, K, N, 1, 1, stream);
+    // the M rows as ONE image of width M: the kernels' pixel walk then never crosses an image
+    // boundary (as M images of 1x1 it would, on every row of every step)
+    return mtn_conv_wgrad(x, ldx, dy, lddy, dw, workspace, ws_bytes, dtype, 1, 1, M, K, N, 1, 1, stream);
 }
 
 int mtn_conv1_stats_tiles(int B, int H, int W) { return mtn_conv1_tiles((long)B * (H / 2) * (W / 2)); }
@@ -264,6 +266,8 @@ int mtn_debug_set(int key, int value) {
     if (key == 3) { mtn_igemm_set_stages(value); return MTN_OK; }
     if (key == 4) { mtn_igemm_set_tile_n64(value); return MTN_OK; }
     if (key == 5) { mtn_wgrad_set_dma(value); return MTN_OK; }
+    if (key == 6) { mtn_igemm_set_tile(value); return MTN_OK; }
+    if (key == 7) { mtn_wgrad_set_tile(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

@@ -434,25 +434,39 @@ int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
     return launch_igemm<T, BM, BN, WGM, WGN, 1>(p, stream);
 }
 
-template <class T>
-int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
-    if (p.N % 128 == 0 && p.M >= 128 * 64) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
-    if (p.N % 128 == 0) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
-    if (g_tile_n64 == 256 && p.M >= 256 * 256) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
-    return launch_igemm_mode<T, 128, 64, 4, 1>(p, stream);
+static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 = 64x128, 3 = 128x64 (N % 128 == 0 only)
+
+// 0: 128x128, 1: 64x128, 2: 256x64, 3: 128x64
+static int igemm_config(int M, int N) {
+    if (N % 128 == 0) {
+        if (g_igemm_tile == 1) return 0;
+        if (g_igemm_tile == 2) return 1;
+        if (g_igemm_tile == 3) return 3;
+        return M >= 128 * 64 ? 0 : 1;
+    }
+    if (g_tile_n64 == 256 && M >= 256 * 256) return 2;
+    return 3;
 }
 
+template <class T>
+int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
+    const int cfg = igemm_config(p.M, p.N);
+    if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
+    if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
+    if (cfg == 2) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
+    return launch_igemm_mode<T, 128, 64, 4, 1>(p, stream);
+}
 }  // namespace
 
 void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 4) ? n : 3; }
 
 void mtn_igemm_set_tile_n64(int rows) { g_tile_n64 = rows == 256 ? 256 : 128; }
 
+void mtn_igemm_set_tile(int t) { g_igemm_tile = t; }
+
 int mtn_igemm_tiles_m(int M, int N) {
-    if (N % 128 == 0 && M >= 128 * 64) return mtn_cdiv(M, 128);
-    if (N % 128 == 0) return mtn_cdiv(M, 64);
-    if (g_tile_n64 == 256 && M >= 256 * 256) return mtn_cdiv(M, 256);
-    return mtn_cdiv(M, 128);
+    static const int bm[4] = {128, 64, 256, 128};
+    return mtn_cdiv(M, bm[igemm_config(M, N)]);
 }
 
 int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {

@@ -128,3 +128,5 @@ int mtn_render_targets_run(const float* joints, const float* vis, float* target,
 int mtn_normalize_image_run(const unsigned char* img, float* out, int B, int H, int W, hipStream_t stream);
 void mtn_igemm_set_tile_n64(int rows);
 void mtn_wgrad_set_dma(int on);
+void mtn_igemm_set_tile(int t);
+void mtn_wgrad_set_tile(int t);

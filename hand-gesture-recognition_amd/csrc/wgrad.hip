@@ -14,6 +14,7 @@
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
+static int g_wgrad_tile = 0;     // debug key 7: 64 forces 64x64 tiles
 static int g_wgrad_dma = 1;      // LDS-DMA pipeline (debug key 5 selects the register-staged one)
 
 namespace {
@@ -362,12 +363,14 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
 
 static int g_use_tr16 = 1;
 void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
+void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
 
 // tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
 static void wgrad_tile(int N, int Cin, int* bn, int* bc) {
     *bn = N % 128 == 0 ? 128 : 64;
     *bc = Cin % 128 == 0 ? 128 : 64;
+    if (g_wgrad_tile == 64) { *bn = 64; *bc = 64; }
     if (*bn == 64 && *bc == 128) *bc = 64;          // (64,128) is not instantiated
 }
 

@@ -34,12 +34,16 @@ def main():
     ap.add_argument("--stages", type=int, default=3)
     ap.add_argument("--n64rows", type=int, default=128)
     ap.add_argument("--wgrad_dma", type=int, default=1)
+    ap.add_argument("--igemm_tile", type=int, default=0)
+    ap.add_argument("--wgrad_tile", type=int, default=0)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from hand_gesture_recognition_amd import lib as _lib
     _lib.call("mtn_debug_set", 3, a.stages)
     _lib.call("mtn_debug_set", 4, a.n64rows)
     _lib.call("mtn_debug_set", 5, a.wgrad_dma)
+    _lib.call("mtn_debug_set", 6, a.igemm_tile)
+    _lib.call("mtn_debug_set", 7, a.wgrad_tile)
     dev = torch.device("cuda:0")
     B = a.batch
     esz = 2 if dt == torch.bfloat16 else 4
@@ -119,9 +123,16 @@ def main():
         lib.call("mtn_debug_set", 2, 0)
     # ViT linears: M = B*145
     M = B * 145
-    for name, K, N in (("qkv", 256, 768), ("out", 256, 256)):
+    for name, K, N in (("qkv", 256, 768), ("out", 256, 256), ("dqkv", 768, 256)):
         if a.filter and a.filter not in "linear." + name:
             continue
+        if name != "dqkv":
+            x = torch.randn(M, K, device=dev).to(dt)
+            dy = torch.randn(M, N, device=dev).to(dt)
+            dw = torch.empty(N, K, device=dev)
+            ws = torch.empty(ops.linear_wgrad_workspace_bytes(dt, M, N, K) // 4, device=dev)
+            t = timeit(lambda: ops.linear_wgrad(x, dy, dw, ws))
+            print(f"linear_wgrad.{name:4s} M={M:8d} N={N:4d} K={K:5d}  {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s  ws={ws.numel()*4/1e6:.0f}MB")
         x = torch.randn(M, K, device=dev).to(dt)
         w = (torch.randn(N, K, device=dev) / 16).to(dt)
         o = torch.empty(M, N, device=dev, dtype=dt)
