@@ -27,7 +27,7 @@ extern "C" {
 const char* mtn_last_error(void) { return g_err; }
 int mtn_abi_version(void) { return 1; }
 
-int mtn_conv_stats_tiles(int M, int Cout) { return mtn_igemm_tiles_m(M, Cout); }
+int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
 int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int dtype,
                  int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {

@@ -437,12 +437,19 @@ int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
 static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 = 64x128, 3 = 128x64 (N % 128 == 0 only)
 
 // 0: 128x128, 1: 64x128, 2: 256x64, 3: 128x64
-static int igemm_config(int M, int N) {
+// 128-wide outputs choose between the 128x128 tile (2 workgroups / CU = 512 slots) and the 64x128
+// tile (3 / CU = 768 slots): the short-K layers are HBM-bound and want the extra loads in flight;
+// otherwise the smaller tile is taken only where it fills the last round of workgroups clearly
+// better (measured per layer in DESIGN.md section 7b: its own main loop is ~12 % slower).
+static int igemm_config(int M, int N, int K) {
     if (N % 128 == 0) {
         if (g_igemm_tile == 1) return 0;
         if (g_igemm_tile == 2) return 1;
         if (g_igemm_tile == 3) return 3;
-        return M >= 128 * 64 ? 0 : 1;
+        if (M < 128 * 64 || K <= 256) return 1;
+        const double x128 = (double)mtn_cdiv(M, 128) * (N / 128) / 512.0, x64 = (double)mtn_cdiv(M, 64) * (N / 128) / 768.0;
+        const double e128 = x128 / (double)(long)(x128 + 0.999999), e64 = x64 / (double)(long)(x64 + 0.999999);
+        return e128 < 0.88 * e64 ? 1 : 0;
     }
     if (g_tile_n64 == 256 && M >= 256 * 256) return 2;
     return 3;
@@ -450,7 +457,7 @@ static int igemm_config(int M, int N) {
 
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
-    const int cfg = igemm_config(p.M, p.N);
+    const int cfg = igemm_config(p.M, p.N, p.K);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
     if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
     if (cfg == 2) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
@@ -464,9 +471,9 @@ void mtn_igemm_set_tile_n64(int rows) { g_tile_n64 = rows == 256 ? 256 : 128; }
 
 void mtn_igemm_set_tile(int t) { g_igemm_tile = t; }
 
-int mtn_igemm_tiles_m(int M, int N) {
+int mtn_igemm_tiles_m(int M, int N, int K) {
     static const int bm[4] = {128, 64, 256, 128};
-    return mtn_cdiv(M, bm[igemm_config(M, N)]);
+    return mtn_cdiv(M, bm[igemm_config(M, N, K)]);
 }
 
 int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {

@@ -29,7 +29,7 @@ struct IgemmArgs {
 };
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
-int mtn_igemm_tiles_m(int M, int N);
+int mtn_igemm_tiles_m(int M, int N, int K);
 
 struct WgradArgs {
     const void* dY; int lddy;     // [M][lddy] output-pixel gradients

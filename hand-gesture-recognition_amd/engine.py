@@ -137,7 +137,7 @@ class Engine:
             u.M = M
             u.raw = self._new((B, u.hout, u.wout, u.cout))
             if u.bn:
-                tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_stats_tiles(M, u.cout)
+                tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_stats_tiles(M, u.cout, u.k * u.k * u.cin)
                 u.tiles = tiles
                 u.stats = self._f32(ops.slab_rows(tiles), 2, u.cout)
                 u.ss, u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout), self._f32(2, u.cout)

@@ -36,8 +36,9 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def conv_stats_tiles(M, cout):
-    return lib.call("mtn_conv_stats_tiles", M, cout)
+def conv_stats_tiles(M, cout, K):
+    """rows of the partial-statistics slab conv_fwd writes (K = ksize*ksize*Cin)."""
+    return lib.call("mtn_conv_stats_tiles", M, cout, K)
 
 
 def conv_fwd(x, w, y, stats, ksize, stride):

@@ -39,8 +39,9 @@ int mtn_abi_version(void);
 
 /* ---- GELAN backbone: Conv2d(bias=False) -> BatchNorm2d(train) -> SiLU  (model/gelan.py:37-56) */
 
-/* number of row tiles whose partial BN statistics mtn_conv_fwd writes: stats is [tiles][2][Cout] */
-int mtn_conv_stats_tiles(int M, int Cout);
+/* number of row tiles whose partial BN statistics mtn_conv_fwd writes: stats is [tiles][2][Cout].
+ * M = B*OH*OW output pixels, K = ksize*ksize*Cin (the tile shape is chosen per layer). */
+int mtn_conv_stats_tiles(int M, int Cout, int K);
 
 /* y_raw = conv(x) (k in {1,3}, pad k/2, stride in {1,2}); w packed [Cout][k][k][Cin];
  * stats (optional) receives per-tile per-channel sum / sum-of-squares of y_raw. */

@@ -47,7 +47,7 @@ def test_conv_fwd_and_stats(be, stages, dtype, cfg):
     M = B * OH * OW
     xd, wd = x.to(be.device), pack_krsc(w, dtype).to(be.device)
     y = torch.full((B, OH, OW, Cout), float("nan"), dtype=dtype, device=be.device)
-    tiles = ops.conv_stats_tiles(M, Cout)
+    tiles = ops.conv_stats_tiles(M, Cout, k * k * Cin)
     stats = torch.full((tiles, 2, Cout), float("nan"), dtype=torch.float32, device=be.device)
     ops.conv_fwd(xd, wd, y, stats, k, s)
     be.sync()
