@@ -17,10 +17,12 @@
 
 namespace {
 
+constexpr int kLanes = 16;            // row lanes of the 1024-thread reduction blocks (x 64 columns)
+
 // out[rb][c] = sum of in[r][c] over the rb-th block of rows_per_block rows
-__global__ __launch_bounds__(256) void rowblock_sum_kernel(const float* __restrict__ in, int rows, int W,
-                                                           int rows_per_block, float* __restrict__ out) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void rowblock_sum_kernel(const float* __restrict__ in, int rows, int W,
+                                                            int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[kLanes][64];
     const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * rows_per_block;
@@ -28,31 +30,35 @@ __global__ __launch_bounds__(256) void rowblock_sum_kernel(const float* __restri
     if (r1 > rows) r1 = rows;
     float s = 0.f;
     if (c < W)
-        for (int r = r0 + tl; r < r1; r += 4) s += in[(long)r * W + c];
+        for (int r = r0 + tl; r < r1; r += kLanes) s += in[(long)r * W + c];
     red[tl][cl] = s;
     __syncthreads();
-    if (tl == 0 && c < W) out[(long)blockIdx.y * W + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (tl == 0 && c < W) {
+        float t = 0.f;
+        MTN_UNROLL for (int q = 0; q < kLanes; ++q) t += red[q][cl];
+        out[(long)blockIdx.y * W + c] = t;
+    }
 }
 
-// block = 4 row-lanes x 64 channels; returns (sum over R rows of part[r][which][c]) in double
+// block = 16 row-lanes x 64 channels; returns (sum over R rows of part[r][which][c]) in double
 __device__ __forceinline__ void sum2_rows(const float* __restrict__ part, int R, int C, int c, bool valid,
                                           double& s0, double& s1) {
-    __shared__ double red[2][4][64];
+    __shared__ double red[2][kLanes][64];
     const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
     if (valid)
-        for (int r = tl; r < R; r += 4) {
+        for (int r = tl; r < R; r += kLanes) {
             a += (double)part[((long)r * 2 + 0) * C + c];
             b += (double)part[((long)r * 2 + 1) * C + c];
         }
     red[0][tl][cl] = a;
     red[1][tl][cl] = b;
     __syncthreads();
-    s0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    s0 = 0.0; s1 = 0.0;
+    MTN_UNROLL for (int q = 0; q < kLanes; ++q) { s0 += red[0][q][cl]; s1 += red[1][q][cl]; }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ rmean, float* __restrict__ rvar,
                                                           long long* __restrict__ nbt, float momentum, float eps,
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float s0[VEC], s1[VEC];
     MTN_UNROLL for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
     if (rl < rl_n)
+#pragma unroll 2
         for (int m = r0 + rl; m < r1; m += rl_n) {
             float dz[VEC], xh[VEC];
             bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, ss, mr, C, act, m, c, dz, xh);
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // dgamma = sum dz*xhat, dbeta = sum dz; coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -228,25 +235,27 @@ inline int ew_grid(long total) {
 
 // ---- host-side launchers -----------------------------------------------------------------------
 static const int kRowsPerBlock = 128;     // rows folded by one rowblock_sum block
-static const int kBwdRows = 256;          // rows per bn_bwd_reduce block (upper bound, see below)
+static const int kDirectRows = 256;       // slabs up to this many rows go straight to the finalize kernels (<= 16 per row lane)
+static const int kBwdBlocks = 2048;       // bn_bwd_reduce grid cap: 256 CUs x 8 resident workgroups, one round
 
 // rows of scratch a slab with `rows` producer rows needs for the folding passes (appended after it)
 int mtn_reduce_rows_needed(int rows) {
     int total = rows;
-    while (rows > kRowsPerBlock) {
+    while (rows > kDirectRows) {
         rows = mtn_cdiv(rows, kRowsPerBlock);
         total += rows;
     }
     return total;
 }
 
-// folds part[rows][W] 128 rows at a time into the scratch rows that follow it until <= 128 rows
-// remain; returns pointer / row count of the small slab the finalize kernel reads
+// folds part[rows][W] 128 rows at a time into the scratch rows that follow it until a finalize
+// kernel takes the rest (16 row lanes x 64 columns per block); returns
+// pointer / row count of the slab the finalize kernel reads
 static int fold_rows(const float*& part, int& rows, int W, hipStream_t stream) {
-    while (rows > kRowsPerBlock) {
+    while (rows > kDirectRows) {
         const int R = mtn_cdiv(rows, kRowsPerBlock);
         float* out = const_cast<float*>(part) + (long)rows * W;
-        MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(256), 0, stream, part, rows, W, kRowsPerBlock, out);
+        MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(1024), 0, stream, part, rows, W, kRowsPerBlock, out);
         int rc = mtn_check_launch("rowblock_sum");
         if (rc) return rc;
         part = out;
@@ -263,7 +272,7 @@ int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float*
     int rows = tiles;
     int rc = fold_rows(part, rows, 2 * C, stream);
     if (rc) return rc;
-    MTN_LAUNCH(bn_finalize_kernel, dim3(mtn_cdiv(C, 64)), dim3(256), 0, stream, part, rows, C, (float)count, gamma, beta,
+    MTN_LAUNCH(bn_finalize_kernel, dim3(mtn_cdiv(C, 64)), dim3(1024), 0, stream, part, rows, C, (float)count, gamma, beta,
                rmean, rvar, nbt, momentum, eps, scale_shift, mean_rstd);
     return mtn_check_launch("bn_finalize");
 }
@@ -290,7 +299,11 @@ int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res,
     return mtn_check_launch("bn_act_fwd");
 }
 
-int mtn_bn_bwd_blocks(int M) { return mtn_cdiv(M, kBwdRows); }
+// one round of resident workgroups at most: a second, partly filled round costs a whole round
+int mtn_bn_bwd_blocks(int M) {
+    const int b = mtn_cdiv(M, 64);
+    return b < kBwdBlocks ? b : kBwdBlocks;
+}
 
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
     const int vec = dtype == MTN_BF16 ? 8 : 4;
@@ -299,22 +312,23 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
     MTN_REQUIRE(a.act == MTN_ACT_NONE || a.act == MTN_ACT_SILU, "bn_bwd: act=%d", a.act);
     MTN_REQUIRE(a.act == MTN_ACT_SILU || !a.res, "bn_bwd: residual needs SiLU");
     const int blocks = mtn_bn_bwd_blocks(a.M);
+    const int rows_per_block = mtn_cdiv(a.M, blocks);
     const size_t lds = (size_t)(256 / cpr) * 2 * a.C * sizeof(float);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)a.dout, a.lddo,
                    (const bf16_t*)a.y, a.ldy, (const bf16_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
-                   kBwdRows, a.partial);
+                   rows_per_block, a.partial);
     else
         MTN_LAUNCH(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), lds, stream, (const float*)a.dout, a.lddo,
                    (const float*)a.y, a.ldy, (const float*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
-                   kBwdRows, a.partial);
+                   rows_per_block, a.partial);
     int rc = mtn_check_launch("bn_bwd_reduce");
     if (rc) return rc;
     const float* part = a.partial;
     int rows = blocks;
     rc = fold_rows(part, rows, 2 * a.C, stream);
     if (rc) return rc;
-    MTN_LAUNCH(bn_bwd_finalize_kernel, dim3(mtn_cdiv(a.C, 64)), dim3(256), 0, stream, part, rows, a.C, (float)a.M,
+    MTN_LAUNCH(bn_bwd_finalize_kernel, dim3(mtn_cdiv(a.C, 64)), dim3(1024), 0, stream, part, rows, a.C, (float)a.M,
                a.dgamma, a.dbeta, a.coef);
     rc = mtn_check_launch("bn_bwd_finalize");
     if (rc) return rc;
@@ -331,26 +345,11 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
 }
 
 // generic ordered column sum of an f32 slab: out[c] = sum_r in[r][c]  (bias / LayerNorm affine grads)
-namespace {
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int R, int W,
-                                                              float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
-    const int c = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (c < W)
-        for (int r = tl; r < R; r += 4) s += part[(long)r * W + c];
-    red[tl][cl] = s;
-    __syncthreads();
-    if (tl == 0 && c < W) out[c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-}
-}  // namespace
-
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream) {
     MTN_REQUIRE(rows > 0 && W > 0, "colsum: bad sizes (%d x %d)", rows, W);
     const float* part = slab;
     int rc = fold_rows(part, rows, W, stream);
     if (rc) return rc;
-    MTN_LAUNCH(colsum_finalize_kernel, dim3(mtn_cdiv(W, 64)), dim3(256), 0, stream, part, rows, W, out);
+    MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), 1), dim3(1024), 0, stream, part, rows, W, rows, out);
     return mtn_check_launch("colsum");
 }
