@@ -121,16 +121,6 @@ __device__ __forceinline__ int attn_bh(int H) {
     return b * H + h;
 }
 
-template <class T> __device__ __forceinline__ void store4(T* dst, f32x4_t v);
-template <> __device__ __forceinline__ void store4<float>(float* dst, f32x4_t v) {
-    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, f32x4_t v) {
-    uint2 u = make_uint2((unsigned)f2bf(v[0]).v | ((unsigned)f2bf(v[1]).v << 16),
-                         (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16));
-    *reinterpret_cast<uint2*>(dst) = u;
-}
-
 // ---- forward ------------------------------------------------------------------------------------
 template <class T, int MAXT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,

@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     constexpr int VEC = 16 / (int)sizeof(T);
     const int cpr = C / VEC;
     const long total = (long)M * cpr;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // rows in DESCENDING order: the reduce pass that just ran left the tail of dout / y in the
+    // memory-side cache, so the re-read starts where it still hits
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long idx = total - 1 - it;
         const int m = (int)(idx / cpr), c = (int)(idx - (long)m * cpr) * VEC;
         float dz[VEC], xh[VEC], o[VEC];
         bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, ss, mr, C, act, m, c, dz, xh);

@@ -268,7 +268,15 @@ int mtn_debug_set(int key, int value) {
     if (key == 5) { mtn_wgrad_set_dma(value); return MTN_OK; }
     if (key == 6) { mtn_igemm_set_tile(value); return MTN_OK; }
     if (key == 7) { mtn_wgrad_set_tile(value); return MTN_OK; }
+    if (key == 8) { mtn_igemm_set_dbg(value); return MTN_OK; }
+    if (key == 9) { mtn_igemm_set_window_limit(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
+    return MTN_ERR_BAD_ARG;
+}
+
+int mtn_debug_read(int key, void* dst, size_t bytes) {
+    if (key == 1) return mtn_igemm_read_stamps(dst, bytes) ? MTN_ERR_BAD_ARG : MTN_OK;
+    mtn_set_error("debug_read: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }
 

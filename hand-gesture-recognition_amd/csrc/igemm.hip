@@ -34,6 +34,15 @@ constexpr int PITCH_BYTES = 144;        // padded LDS row (register-staged pipel
 // write zeros by itself)
 __device__ unsigned g_zero_page[64];
 
+// In-kernel phase stamps (diagnostic builds only: make hip EXTRA=-DMTN_STAMPS; the shipped library
+// has none).  Wave 0 of the first 256 workgroups sums the cycles of each phase of its K loop.
+#ifdef MTN_STAMPS
+__device__ unsigned long long g_stamps[256 * 8];
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var)
+#endif
+
 // One wave-instruction of LDS-DMA: lane l copies 16 bytes from its own global address to
 // lds_block + 16*l (the destination is wave-uniform base + lane*16 -- cdna_hip_programming.md
 // section 5, "Async global->LDS copy"); no VGPR staging, no ds_write.
@@ -52,8 +61,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
 // STAGES = 3: LDS-DMA (global_load_lds 16 B) into two unpadded, XOR-swizzled LDS buffers: the
 //             swizzle is applied to the per-lane SOURCE chunk and to the fragment read, the LDS
 //             image itself is lane-linear (rule 21).  One barrier per K step, no staging VGPRs.
+// STAGES = 5: "window" mode for stride-1 3x3 taps (forward and data gradient).  In the flattened
+//             (b, y, x) pixel order tap (kh, kw) of output row m reads input row m + dy*W + dx, so
+//             the BM rows of a tile need only the CONTIGUOUS input rows [m0 - W - 1, m0 + BM + W + 1).
+//             That window (up to 128 channels at a time) is DMA-ed into LDS once per tile and every
+//             tap reads its A fragments from it at a row offset; rows whose tap falls into the zero
+//             padding read a zero row instead (the neighbouring image row / image the shift would
+//             hit is exactly the padded case).  Only the weight tiles stream per K step: the
+//             activation operand crosses the L2 -> LDS path ~1.2-1.8x instead of 9x per tile.
+// LDS allows two 128x128 workgroups (three of the smaller tiles) per CU: telling the compiler so
+// lets its scheduler spend registers on keeping the fragment reads of a K step in flight instead
+// of minimising pressure for an occupancy the LDS footprint rules out anyway.
+#ifdef MTN_EMU
+#define MTN_WAVES_PER_SIMD(n)
+#else
+#define MTN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(1, n)))
+#endif
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
-__global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
+__global__ __launch_bounds__(WGM* WGN * 64) MTN_WAVES_PER_SIMD((BM * BN >= 128 * 128 ? 2 : 3))
+void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int BK = ROW_BYTES / (int)sizeof(T);
     constexpr int PITCH = PITCH_BYTES / (int)sizeof(T);
@@ -66,14 +92,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     constexpr int RSTEP = NT / 8;        // rows between a thread's chunks
     typedef typename std::conditional<STAGES != 2, T, float>::type CT;     // staged C element
     constexpr bool DMA = STAGES >= 3;
+    constexpr bool WIN = STAGES == 5;
     constexpr int NBUF = STAGES == 1 ? 1 : (STAGES == 4 ? 3 : 2);
     constexpr int PITCH_E = DMA ? BK : PITCH;                              // LDS row pitch in elements
     constexpr int CP = BN + 16 / (int)sizeof(CT);                          // pitch of the staged C tile
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "loader mapping");
 
     MTN_DYN_SMEM(smem);
-    T* const sA = reinterpret_cast<T*>(smem);                       // [NBUF][BM][PITCH_E]
-    T* const sB = sA + NBUF * BM * PITCH_E;                         // [NBUF][BN][PITCH_E]
+    T* const sA = reinterpret_cast<T*>(smem);                       // [NBUF][BM][PITCH_E]  (WIN: unused)
+    T* const sB = WIN ? sA : sA + NBUF * BM * PITCH_E;              // [NBUF][BN][PITCH_E]
+    // WIN: window rows per channel slab (multiple of 8), resident 128-byte channel slabs, their
+    // number of passes over Cin, and the LDS regions [CS][WR8][BK] window + one zero row
+    const int win_halo = WIN ? p.W + 1 : 0;
+    const int WR8 = (BM + 2 * win_halo + 7) & ~7;
+    const int CS = p.Cin / BK >= 2 ? 2 : 1;
+    T* const sWin = sB + 2 * BN * BK;
+    T* const sZero = sWin + CS * WR8 * BK;
     CT* const sC = reinterpret_cast<CT*>(smem);                     // [BM][CP] (after the K loop)
 
     const int tid = threadIdx.x;
@@ -146,7 +180,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     unsigned my_taps = 0;
     MTN_UNROLL for (int i = 0; i < RA; ++i) {
         const int m = m0 + row0 + i * rstep_a;
-        if (m < p.M) {
+        if (!WIN && m < p.M) {
             int b, oy, ox;
             decode(m, b, oy, ox);
             a_y[i] = oy * p.mul + p.off;
@@ -221,11 +255,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
         char* a = reinterpret_cast<char*>(sA + stage * BM * PITCH_E);
         char* b = reinterpret_cast<char*>(sB + stage * BN * PITCH_E);
         const int cc = c0 + chunk * VEC;
+        if (!(p.dbg == 1 && kt > 0))
         MTN_UNROLL for (int i = 0; i < RA; ++i) {
             const int iy = (a_y[i] + kh * p.sgn) >> dshift, ix = (a_x[i] + kw * p.sgn) >> dshift;
             const unsigned e = (unsigned)((a_base[i] + iy * p.W + ix) * p.lda + cc) * (unsigned)sizeof(T);
             buf_glds16(bufA, (((a_vy[i] >> kh) & (a_vx[i] >> kw)) & 1u) ? e : 0xFFFFFFF0u, a + (wid * RA + i) * 1024);
         }
+        if (!(p.dbg == 2 && kt > 0))
         MTN_UNROLL for (int i = 0; i < RB; ++i)
             buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
                        b + (wid * RB + i) * 1024);
@@ -247,21 +283,96 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
     const int frow = lane & 15;
     const int fk = (lane >> 4) * (KI / 4);
 
+    // One K step of MFMAs with the fragment reads software-pipelined by hand: W fragments of a
+    // k-substep, then A fragments two ahead of the row of MFMAs that consumes them.  The scheduler
+    // fences pin that order -- left alone, hipcc reads one A fragment, waits for it, issues its
+    // row of MFMAs, reads the next (in-kernel stamps: 640-1100 cycles per step for 512 of MFMA).
+    auto mma_step = [&](auto&& loadA, auto&& loadB) {
+        constexpr int KS = BK / KI, NA = KS * FM;
+        typename Mma<T>::Frag fb[KS][FN], fa[NA];
+        MTN_UNROLL for (int j = 0; j < FN; ++j) fb[0][j] = loadB(0, j);
+        fa[0] = loadA(0, 0);
+        if (NA > 1) fa[1] = loadA(1 / FM, 1 % FM);
+        MTN_SCHED_FENCE();
+        MTN_UNROLL for (int k = 0; k < NA; ++k) {
+            if (k % FM == 0 && k / FM + 1 < KS) {
+                MTN_UNROLL for (int j = 0; j < FN; ++j) fb[k / FM + 1][j] = loadB(k / FM + 1, j);
+            }
+            if (k + 2 < NA) fa[k + 2] = loadA((k + 2) / FM, (k + 2) % FM);
+            MTN_UNROLL for (int j = 0; j < FN; ++j) acc[k % FM][j] = Mma<T>::mma(fb[k / FM][j], fa[k], acc[k % FM][j]);
+            MTN_SCHED_FENCE();
+        }
+    };
+    // WIN: per fragment row of this lane, which tap rows / columns read a stored pixel
+    unsigned f_vy[FM], f_vx[FM];
+    if (WIN) {
+        MTN_UNROLL for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + frow;
+            unsigned vy = 0, vx = 0;
+            if (m < p.M) {
+                int b, oy, ox;
+                decode(m, b, oy, ox);
+                MTN_UNROLL for (int t = 0; t < 3; ++t) {
+                    const int ty = oy + t * p.sgn + p.off, tx = ox + t * p.sgn + p.off;
+                    if (ty >= 0 && ty < p.H) vy |= 1u << t;
+                    if (tx >= 0 && tx < p.W) vx |= 1u << t;
+                }
+            }
+            f_vy[i] = vy; f_vx[i] = vx;
+        }
+        if (tid < 128 / 4) reinterpret_cast<unsigned*>(sZero)[tid] = 0u;
+    }
+    const int win_total = p.B * p.H * p.W;                 // rows of the gather source
+    // DMA of channel slab `slab` (CS x BK channels) of the window rows into sWin
+    auto dma_window = [&](int slab) {
+        const int ppc = WR8 >> 3;                          // 1 KiB pieces per BK-channel slab
+        for (int q = wid; q < CS * ppc; q += NT / 64) {
+            const int cs = q / ppc, pr = q - cs * ppc;
+            const int j = pr * 8 + (lane >> 3);
+            const int g = m0 - win_halo + j;
+            const int ch = (slab * CS + cs) * BK + (((lane & 7) ^ (lane >> 3)) * VEC);
+            const unsigned e = (unsigned)(g * p.lda + ch) * (unsigned)sizeof(T);
+            buf_glds16(bufA, (g >= 0 && g < win_total) ? e : 0xFFFFFFF0u,
+                       reinterpret_cast<char*>(sWin + (cs * WR8 + pr * 8) * BK));
+        }
+    };
+    // W tile of window-mode K step kk of slab `slab` (order: tap outer, resident channel slab inner)
+    auto dma_w = [&](int slab, int kk, int stage) {
+        const int tap = kk / CS, cs = kk - tap * CS;
+        const int k0 = tap * p.Cin + (slab * CS + cs) * BK;
+        char* b = reinterpret_cast<char*>(sB + stage * BN * BK);
+        MTN_UNROLL for (int i = 0; i < RB; ++i)
+            buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
+                       b + (wid * RB + i) * 1024);
+    };
+    auto compute_win = [&](int kk, int stage) {
+        const int tap = kk / CS, cs = kk - tap * CS;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int delta = (kh * p.sgn + p.off) * p.W + (kw * p.sgn + p.off) + win_halo;
+        const T* b = sB + stage * BN * BK + (wn * WN + frow) * BK;
+        const int swb = frow & 7;
+        // A fragment positions as element offsets from the LDS base (window row or the zero row)
+        int aoff[FM];
+        int asw[FM];
+        MTN_UNROLL for (int i = 0; i < FM; ++i) {
+            const int j = wm * WM + i * 16 + frow + delta;
+            const bool ok = ((f_vy[i] >> kh) & (f_vx[i] >> kw)) & 1u;
+            aoff[i] = ok ? (2 * BN + cs * WR8 + j) * BK : (2 * BN + CS * WR8) * BK;
+            asw[i] = j & 7;
+        }
+        mma_step([&](int ks, int i) { const int e = ks * KI + fk; return Mma<T>::load(sB + aoff[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC)); },
+                 [&](int ks, int j) { const int e = ks * KI + fk; return Mma<T>::load(b + j * 16 * BK + (((e / VEC) ^ swb) * VEC) + (e % VEC)); });
+    };
+
     auto compute = [&](int stage) {
         if (DMA) {
             // fragment element offset ks*KI+fk -> 16-byte slot (ks*KI+fk)/VEC, swizzled by row & 7
             const T* a = sA + stage * BM * BK + (wm * WM + frow) * BK;
             const T* b = sB + stage * BN * BK + (wn * WN + frow) * BK;
             const int sw = frow & 7;                       // (row & 7): tile bases are multiples of 16
-            MTN_UNROLL for (int ks = 0; ks < BK / KI; ++ks) {
-                const int e = ks * KI + fk;
-                const int off = (((e / VEC) ^ sw) * VEC) + (e % VEC);
-                typename Mma<T>::Frag fa[FM], fb[FN];
-                MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = Mma<T>::load(a + i * 16 * BK + off);
-                MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = Mma<T>::load(b + j * 16 * BK + off);
-                MTN_UNROLL for (int i = 0; i < FM; ++i)
-                    MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
-            }
+            auto off = [&](int ks) { const int e = ks * KI + fk; return (((e / VEC) ^ sw) * VEC) + (e % VEC); };
+            mma_step([&](int ks, int i) { return Mma<T>::load(a + i * 16 * BK + off(ks)); },
+                     [&](int ks, int j) { return Mma<T>::load(b + j * 16 * BK + off(ks)); });
             return;
         }
         const T* a = sA + stage * BM * PITCH + (wm * WM + frow) * PITCH + fk;
@@ -271,10 +382,40 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = Mma<T>::load(a + i * 16 * PITCH + ks * KI);
             MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = Mma<T>::load(b + j * 16 * PITCH + ks * KI);
             MTN_UNROLL for (int i = 0; i < FM; ++i)
-                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
         }
     };
-    if (STAGES == 4) {
+#ifdef MTN_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+    if (WIN) {
+        const int slabs = p.Cin / (CS * BK), steps = 9 * CS;
+        for (int slab = 0; slab < slabs; ++slab) {
+            __syncthreads();                               // the previous window / W tiles are consumed
+            STAMP(tw0);
+            dma_window(slab);
+            dma_w(slab, 0, 0);
+            __syncthreads();
+            STAMP(tw1);
+#ifdef MTN_STAMPS
+            st_acc[0] += tw1 - tw0;
+#endif
+            for (int kk = 0; kk < steps; ++kk) {
+                const int cur = kk & 1;
+                STAMP(t0);
+                if (kk + 1 < steps) dma_w(slab, kk + 1, cur ^ 1);
+                STAMP(t1);
+                compute_win(kk, cur);
+                STAMP(t2);
+                __syncthreads();
+                STAMP(t3);
+#ifdef MTN_STAMPS
+                st_acc[1] += t1 - t0; st_acc[2] += t2 - t1; st_acc[3] += t3 - t2; st_acc[4] += 1;
+#endif
+            }
+        }
+    } else if (STAGES == 4) {
         // three buffers, loads TWO tiles ahead: a counted vmcnt leaves the youngest tile in flight
         // across a raw s_barrier (a __syncthreads() here would drain it: its fence waits vmcnt(0))
         if (KT > 0) dma_tiles(0, 0);
@@ -309,9 +450,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
+            STAMP(t0);
             if (kt + 1 < KT) dma_tiles(kt + 1, cur ^ 1);
+            STAMP(t1);
             compute(cur);
+            STAMP(t2);
             __syncthreads();
+            STAMP(t3);
+#ifdef MTN_STAMPS
+            st_acc[1] += t1 - t0; st_acc[2] += t2 - t1; st_acc[3] += t3 - t2; st_acc[4] += 1;
+#endif
         }
     } else
     if (STAGES == 2) {
@@ -338,11 +486,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
         }
     }
 
+#ifdef MTN_STAMPS
+    const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: accumulators -> LDS (f32) -> row-wise fused math -> 16-byte stores ----------
+    // The MFMAs take the W fragment as their row operand, so a lane's four accumulator registers
+    // are four CONSECUTIVE channels of one pixel: one 8- / 16-byte LDS store per fragment instead
+    // of four scattered element stores.
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j)
-            MTN_UNROLL for (int r = 0; r < 4; ++r)
-                sC[(wm * WM + i * 16 + 4 * (lane >> 4) + r) * CP + wn * WN + j * 16 + (lane & 15)] = from_f<CT>(acc[i][j][r]);
+            store4<CT>(sC + (wm * WM + i * 16 + (lane & 15)) * CP + wn * WN + j * 16 + 4 * (lane >> 4), acc[i][j]);
     __syncthreads();
 
     T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
@@ -399,6 +552,34 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IgemmArgs p) {
             p.stats[((long)tile_m * 2 + which) * p.N + n0 + c] = t;
         }
     }
+#ifdef MTN_STAMPS
+    if (tid == 0 && blockIdx.x < 256) {
+        const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = g_stamps + blockIdx.x * 8;
+        o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[2]; o[3] = st_acc[3]; o[4] = st_acc[4];
+        o[5] = st_loop_end - st_begin; o[6] = st_end - st_loop_end; o[7] = st_begin;
+    }
+#endif
+}
+
+// LDS bytes of the window mode: two W tiles + the window rows of the resident channel slabs + a zero row
+static size_t igemm_window_bytes(const IgemmArgs& p, int bm, int bn, int esz) {
+    const int bk = ROW_BYTES / esz;
+    const int cs = p.Cin / bk >= 2 ? 2 : 1;
+    const size_t wr8 = (size_t)((bm + 2 * (p.W + 1) + 7) & ~7);
+    return (2 * (size_t)bn + cs * wr8 + 1) * ROW_BYTES;
+}
+
+// window mode serves stride-1 3x3 taps whose LDS footprint still lets three workgroups share a CU
+// (53 KB): measured per layer it wins 25 % there (64-channel stage-1
+// layers) and loses to the plain LDS-DMA pipeline once the window costs a resident workgroup.
+// Debug key 9 raises the limit (tests run every shape through the window path).
+static int g_window_limit_kb = 53;
+static bool igemm_window_ok(const IgemmArgs& p, int bm, int bn, int esz) {
+    const int bk = ROW_BYTES / esz;
+    const int cs = p.Cin / bk >= 2 ? 2 : 1;
+    return p.KH == 3 && p.KW == 3 && p.mul == 1 && p.div == 1 && !p.pm && p.OH == p.H && p.OW == p.W &&
+           p.Cin % (cs * bk) == 0 && igemm_window_bytes(p, bm, bn, esz) <= (size_t)g_window_limit_kb * 1024;
 }
 
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
@@ -409,12 +590,17 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr size_t lds_c = (size_t)BM * (BN * csz + 16);
     constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
     constexpr size_t lds0 = lds_ab > lds_c ? lds_ab : lds_c;
-    constexpr size_t lds = lds0 > lds_r ? lds0 : lds_r;
+    size_t lds = lds0 > lds_r ? lds0 : lds_r;
+    if (STAGES == 5) {
+        const size_t win = igemm_window_bytes(p, BM, BN, (int)sizeof(T));
+        const size_t rest = lds_c > lds_r ? lds_c : lds_r;
+        lds = win > rest ? win : rest;
+    }
 #ifndef MTN_EMU
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN, STAGES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, STAGES == 5 ? 160 * 1024 : (int)lds);
         attr_set = true;
     }
 #endif
@@ -424,10 +610,14 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
 }
 
 static int g_tile_n64 = 128;     // rows per tile for 64-wide outputs (debug key 4)
-static int g_igemm_stages = 3;   // LDS-DMA double buffer (measured fastest: see DESIGN.md section 4)
+static int g_igemm_stages = 5;   // window mode where it pays, LDS-DMA double buffer elsewhere
 
 template <class T, int BM, int BN, int WGM, int WGN>
 int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
+    if (g_igemm_stages == 5) {
+        if (igemm_window_ok(p, BM, BN, (int)sizeof(T))) return launch_igemm<T, BM, BN, WGM, WGN, 5>(p, stream);
+        return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
+    }
     if (g_igemm_stages == 4) return launch_igemm<T, BM, BN, WGM, WGN, 4>(p, stream);
     if (g_igemm_stages == 3) return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
     if (g_igemm_stages == 2) return launch_igemm<T, BM, BN, WGM, WGN, 2>(p, stream);
@@ -465,11 +655,23 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
 }
 }  // namespace
 
-void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 4) ? n : 3; }
+void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 5) ? n : 5; }
+void mtn_igemm_set_window_limit(int kb) { g_window_limit_kb = (kb > 0 && kb <= 150) ? kb : 53; }
 
 void mtn_igemm_set_tile_n64(int rows) { g_tile_n64 = rows == 256 ? 256 : 128; }
 
 void mtn_igemm_set_tile(int t) { g_igemm_tile = t; }
+int mtn_igemm_read_stamps(void* dst, size_t bytes) {
+#if defined(MTN_STAMPS) && !defined(MTN_EMU)
+    if (bytes > sizeof(unsigned long long) * 256 * 8) bytes = sizeof(unsigned long long) * 256 * 8;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+#else
+    (void)dst; (void)bytes;
+    return 1;
+#endif
+}
+static int g_igemm_dbg = 0;
+void mtn_igemm_set_dbg(int v) { g_igemm_dbg = v; }
 
 int mtn_igemm_tiles_m(int M, int N, int K) {
     static const int bm[4] = {128, 64, 256, 128};
@@ -478,6 +680,7 @@ int mtn_igemm_tiles_m(int M, int N, int K) {
 
 int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     IgemmArgs p = p0;
+    p.dbg = g_igemm_dbg;
     {   // magic = floor(2^32 / d) + 1: __umulhi(x, magic) == x / d for x * d < 2^32
         const unsigned dw = (unsigned)(p.pm ? p.OW / 2 : p.OW), dh = (unsigned)(p.pm ? p.OH / 2 : p.OH);
         const size_t esz = dtype == MTN_BF16 ? 2 : 4;

@@ -26,6 +26,7 @@ struct IgemmArgs {
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
     unsigned a_bytes, w_bytes;   // filled by mtn_igemm_run: byte extents of A / Wp (buffer descriptors)
+    int dbg;                     // timing experiments only (debug key 8): 1 = skip the A loads after step 0, 2 = skip W
 };
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
@@ -129,4 +130,7 @@ int mtn_normalize_image_run(const unsigned char* img, float* out, int B, int H, 
 void mtn_igemm_set_tile_n64(int rows);
 void mtn_wgrad_set_dma(int on);
 void mtn_igemm_set_tile(int t);
+void mtn_igemm_set_dbg(int v);
+void mtn_igemm_set_window_limit(int kb);
+int mtn_igemm_read_stamps(void* dst, size_t bytes);
 void mtn_wgrad_set_tile(int t);

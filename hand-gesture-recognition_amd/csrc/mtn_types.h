@@ -83,12 +83,39 @@ template <> __device__ __forceinline__ chunk16 pack<bf16_t>(const float* f) {
         c[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
     return c;
 }
+// four consecutive elements from one accumulator quad (dst 8- / 16-byte aligned)
+template <class T> __device__ __forceinline__ void store4(T* dst, const f32x4_t& v);
+template <> __device__ __forceinline__ void store4<float>(float* dst, const f32x4_t& v) {
+#ifdef MTN_EMU
+    MTN_UNROLL for (int r = 0; r < 4; ++r) dst[r] = v[r];
+#else
+    *reinterpret_cast<f32x4_t*>(dst) = v;
+#endif
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const f32x4_t& v) {
+#ifdef MTN_EMU
+    MTN_UNROLL for (int r = 0; r < 4; ++r) dst[r] = f2bf(v[r]);
+#else
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t o;
+    o[0] = (unsigned)f2bf(v[0]).v | ((unsigned)f2bf(v[1]).v << 16);
+    o[1] = (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16);
+    *reinterpret_cast<u32x2_t*>(dst) = o;
+#endif
+}
 __device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c[0] = 0u; c[1] = 0u; c[2] = 0u; c[3] = 0u; return c; }
 
 // ---- MFMA, 16x16 output tile -------------------------------------------------------------
 // Mma<T>::KI = K depth of one instruction; Frag = one lane's A or B operand.
 // Lane map (cdna_hip_programming.md section 3): bf16: A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
 // f32: A[l&15][l>>4], B[l>>4][l&15];  D: col = l&15, row = 4*(l>>4)+reg.
+// scheduler fence: no instruction is moved across it (hand-placed software pipelines)
+#ifdef MTN_EMU
+#define MTN_SCHED_FENCE() ((void)0)
+#else
+#define MTN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 template <class T> struct Mma;
 template <> struct Mma<bf16_t> {
     static constexpr int KI = 32;

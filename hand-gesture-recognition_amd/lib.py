@@ -59,6 +59,7 @@ _PROTOS = {
     "mtn_render_targets": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_normalize_image": [_vp, _vp, _i, _i, _i, _vp],
     "mtn_debug_set": [_i, _i],
+    "mtn_debug_read": [_i, _vp, _sz],
 }
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}
 _STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_wgrad_workspace_bytes",

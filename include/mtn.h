@@ -205,10 +205,15 @@ int mtn_render_targets(const float* joints, const float* vis, float* target, flo
 /* uint8 HWC image batch (cv2 order) -> fp32 NCHW, /255 then ImageNet mean/std (libs/load.py:46-50) */
 int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B, int H, int W, void* stream);
 
-/* test / tuning hook: key 1 = ds_read_b64_tr_b16 operand reads in wgrad (default 1);
+/* test / tuning hooks.  mtn_debug_set: key 1 = ds_read_b64_tr_b16 operand reads in wgrad (default 1);
  * key 3 = igemm pipeline (1: register-staged single LDS buffer; 2: register-staged double buffer;
- *         3: LDS-DMA double buffer (default); 4: LDS-DMA triple buffer with counted vmcnt) */
+ *         3: LDS-DMA double buffer; 4: LDS-DMA triple buffer with counted vmcnt; 5: window-resident
+ *         activations for stride-1 3x3 layers, LDS-DMA double buffer elsewhere);
+ * keys 4-8: tile / split overrides of the tuning tools (tools/bench_kernels.py).
+ * mtn_debug_read: key 1 = in-kernel phase stamps of the last igemm launch (diagnostic builds with
+ * -DMTN_STAMPS only; returns non-zero otherwise). */
 int mtn_debug_set(int key, int value);
+int mtn_debug_read(int key, void* dst, size_t bytes);
 
 #ifdef __cplusplus
 }

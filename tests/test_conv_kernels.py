@@ -20,13 +20,16 @@ def pack_crsk(w_oihw, dtype):       # dgrad operand [I,kh,kw,O]
     return w_oihw.permute(1, 2, 3, 0).contiguous().to(dtype)
 
 
-@pytest.fixture(params=[1, 2, 3, 4], ids=["lds1", "lds2", "dma2", "dma3"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["lds1", "lds2", "dma2", "dma3", "win"])
 def stages(request, be):
-    """all igemm pipelines: register-staged (1 or 2 LDS buffers) and LDS-DMA (2 buffers = default, 3 buffers)"""
+    """all igemm pipelines: register-staged (1 or 2 LDS buffers), LDS-DMA (2 or 3 buffers) and the
+    window-resident mode of the stride-1 3x3 layers (other layers fall back to dma2)"""
     from hand_gesture_recognition_amd import lib
     lib.call("mtn_debug_set", 3, request.param)
+    lib.call("mtn_debug_set", 9, 150)       # every stride-1 3x3 shape goes through the window path
     yield request.param
-    lib.call("mtn_debug_set", 3, 3)
+    lib.call("mtn_debug_set", 3, 5)
+    lib.call("mtn_debug_set", 9, 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -36,6 +39,8 @@ def stages(request, be):
     (1, 8, 8, 64, 128, 3, 2),
     (3, 5, 7, 128, 64, 1, 1),
     (1, 12, 12, 64, 256, 3, 1),
+    (3, 5, 7, 128, 128, 3, 1),
+    (2, 9, 6, 256, 64, 3, 1),
 ])
 def test_conv_fwd_and_stats(be, stages, dtype, cfg):
     B, H, W, Cin, Cout, k, s = cfg
@@ -79,6 +84,8 @@ def test_conv_fwd_channel_slices(be, dtype):
     (1, 8, 8, 64, 128, 3, 2),
     (1, 10, 6, 64, 64, 3, 2),
     (2, 4, 4, 128, 64, 1, 1),
+    (3, 5, 7, 128, 128, 3, 1),
+    (2, 9, 6, 64, 256, 3, 1),
 ])
 def test_conv_dgrad(be, stages, dtype, cfg):
     B, H, W, Cin, Cout, k, s = cfg

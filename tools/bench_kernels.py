@@ -31,11 +31,12 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--filter", default="")
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--stages", type=int, default=3)
+    ap.add_argument("--stages", type=int, default=5)
     ap.add_argument("--n64rows", type=int, default=128)
     ap.add_argument("--wgrad_dma", type=int, default=1)
     ap.add_argument("--igemm_tile", type=int, default=0)
     ap.add_argument("--wgrad_tile", type=int, default=0)
+    ap.add_argument("--igemm_dbg", type=int, default=0)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from hand_gesture_recognition_amd import lib as _lib
@@ -44,6 +45,7 @@ def main():
     _lib.call("mtn_debug_set", 5, a.wgrad_dma)
     _lib.call("mtn_debug_set", 6, a.igemm_tile)
     _lib.call("mtn_debug_set", 7, a.wgrad_tile)
+    _lib.call("mtn_debug_set", 8, a.igemm_dbg)
     dev = torch.device("cuda:0")
     B = a.batch
     esz = 2 if dt == torch.bfloat16 else 4
