@@ -260,6 +260,243 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const T* __restrict__ tok
     }
 }
 
+// Backward on MFMA.  block = (32-channel chunk, image); the heat-map gradient streams through LDS
+// RB output rows (<= 96 pixels) at a time and every contraction runs on the matrix cores:
+//   Y_r[sx][c]  = (1-wy) S[y0][sx][c] + wy S[y1][sx][c]          VALU (rows of the bilinear map)
+//   R_r[ox][c]  = relu(sum_sx X[ox][sx] Y_r[sx][c])              MFMA in f32 (exact products: the sign of u
+//                                                                  decides the ReLU mask, a rounded operand
+//                                                                  would flip it where u ~ 0), K = source columns
+//   dW[j][c]   += sum_p D[j][p] R[p][c]                           MFMA, K = pixels   (accumulates in registers)
+//   G[p][c]     = [R > 0] sum_j D[j][p] W[j][c]                   MFMA, K = 32 joints (zero padded)
+//   T_r[sx][c]  = sum_ox X[ox][sx] G_r[ox][c]                     MFMA, K = output columns (transposed stencil)
+//   dS[y0] += (1-wy) T_r, dS[y1] += wy T_r                        registers: output rows arrive in order and
+//        touch source rows y0, y0+1 with y0 non-decreasing in steps of one, so two running sums per
+//        owned (sx, c) suffice and each source row is written to dtok exactly once.
+// X is the [OW x w] x-interpolation matrix (align_corners=True), kept in LDS in T; operands that
+// are contracted along their LDS rows are read with the transposing fragment read (ColFrag).
+// One writer per output element everywhere: deterministic, no atomics, no block-level reduction.
+constexpr int PB_CC = 32;             // channels per workgroup
+constexpr int PB_MAXPX = 96;          // pixels per streamed tile (RB rows of OW)
+constexpr int PB_MAXRB = 4;
+template <class T> struct PoseLay {   // LDS pitches (elements): +16 bytes per row
+    static constexpr int PAD = 16 / (int)sizeof(T);
+    static constexpr int PR = PB_CC + PAD;        // rows of channels
+    static constexpr int PD = PB_MAXPX + PAD;     // rows of pixels
+    static constexpr int PW = 32 + PAD;           // rows of joints / source columns
+};
+// LDS bytes: T-typed tiles + the f32 interpolation operands + the y tap tables
+template <class T>
+static size_t pose_bwd_mma_bytes(int h, int w, int rb) {
+    const int OW = 4 * w, OWK = (OW + 31) & ~31, OWM = (OW + 15) & ~15, WK4 = (w + 3) & ~3;
+    const size_t t_elems = (size_t)h * w * PB_CC + (size_t)OWK * PoseLay<T>::PW + (size_t)PB_MAXPX * PoseLay<T>::PR +
+                           (size_t)(PB_MAXPX + 32) * PoseLay<T>::PR + 32 * (size_t)PoseLay<T>::PD + PB_CC * (size_t)PoseLay<T>::PW;
+    const size_t f_elems = (size_t)rb * WK4 * (PB_CC + 4) + (size_t)OWM * (WK4 + 4) + 3 * (size_t)(4 * h);
+    return t_elems * sizeof(T) + f_elems * 4;
+}
+template <class T>
+__global__ __launch_bounds__(256) void pose_bwd_mma_kernel(const T* __restrict__ tok, const float* __restrict__ W,
+                                                           const float* __restrict__ dhm, T* __restrict__ dtok,
+                                                           float* __restrict__ slab, int h, int w, int J, int RB_, int skip) {
+    constexpr int CC = PB_CC;
+    constexpr int PR = PoseLay<T>::PR, PD = PoseLay<T>::PD, PW = PoseLay<T>::PW;
+    constexpr int KI = Mma<T>::KI;
+    constexpr bool TR = sizeof(T) == 2;
+    MTN_DYN_SMEM(smem);
+    const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW;
+    const int RP = RB_ * OW, RPK = (RP + 31) & ~31;     // pixels per tile, padded to whole K steps
+    const int OWM = (OW + 15) & ~15, OWK = (OW + 31) & ~31, MW = (w + 15) >> 4, WK4 = (w + 3) & ~3;
+    constexpr int PYF = CC + 4;                         // f32 pitches
+    const int PXF = WK4 + 4;
+    float* sYf = reinterpret_cast<float*>(smem);        // y-interpolated rows [RB][WK4 sx][PYF] f32 (sx >= w: zero)
+    float* sXf = sYf + RB_ * WK4 * PYF;                 // x-interpolation matrix [OWM ox][PXF] f32 (zero padded)
+    int* tY0 = reinterpret_cast<int*>(sXf + OWM * PXF); // [OH] y taps
+    int* tY1 = tY0 + OH;
+    float* tWy = reinterpret_cast<float*>(tY1 + OH);
+    T* sS = reinterpret_cast<T*>(tWy + OH);             // source tokens [hw][CC]
+    T* sX = sS + hw * CC;                               // x-interpolation matrix in T [OWK ox][PW] (scatter operand)
+    T* sR = sX + OWK * PW;                              // relu(u) [MAXPX][PR]
+    T* sG = sR + PB_MAXPX * PR;                         // masked G [MAXPX + 32][PR] (tail rows: zero)
+    T* sD = sG + (PB_MAXPX + 32) * PR;                  // heat-map gradient [32 j][PD]
+    T* sW = sD + 32 * PD;                               // weights [CC][PW] (channel-major, joints contiguous)
+    constexpr int NCH = DIM / CC;
+    int b, chunk;
+    {
+        const int L = blockIdx.x, B = gridDim.x / NCH;
+        if (B % 8 == 0) { const int xcd = L & 7, j = L >> 3; b = (j / NCH) * 8 + xcd; chunk = j % NCH; }
+        else { b = L / NCH; chunk = L % NCH; }
+    }
+    const int c0 = chunk * CC;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + c0;
+    for (int i = tid; i < hw * (CC / 2); i += 256) {    // pairs of channels keep the copy 4 / 8 bytes wide
+        const int p = i / (CC / 2), cc = (i - p * (CC / 2)) * 2;
+        sS[p * CC + cc] = base[(long)p * DIM + cc];
+        sS[p * CC + cc + 1] = base[(long)p * DIM + cc + 1];
+    }
+    for (int i = tid; i < CC * 32; i += 256) {          // W^T chunk, joints zero padded to 32
+        const int cc = i >> 5, j = i & 31;
+        sW[cc * PW + j] = from_f<T>(j < J ? W[j * DIM + c0 + cc] : 0.f);
+    }
+    for (int i = tid; i < OWK * 32; i += 256) {         // X[ox][sx]
+        const int ox = i >> 5, sx = i & 31;
+        float v = 0.f;
+        if (ox < OW && sx < w) {
+            const Lerp l = lerp_coord(ox, w, OW);
+            v = (l.i0 == sx ? 1.f - l.w1 : 0.f) + ((l.i1 == sx && l.i1 != l.i0) ? l.w1 : 0.f);
+        }
+        sX[ox * PW + sx] = from_f<T>(v);
+        if (ox < OWM && sx < WK4) sXf[ox * PXF + sx] = v;
+    }
+    for (int i = tid; i < RB_ * WK4 * PYF; i += 256) sYf[i] = 0.f;
+    for (int i = tid; i < (PB_MAXPX + 32) * PR; i += 256) sG[i] = from_f<T>(0.f);
+    for (int i = tid; i < OH; i += 256) {
+        const Lerp l = lerp_coord(i, h, OH);
+        tY0[i] = l.i0; tY1[i] = l.i1; tWy[i] = l.w1;
+    }
+    const float* dh = dhm + (long)b * J * OHW;
+    const bool do_bias = chunk == 0;
+    const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
+    const int jt = wid >> 1, ct = wid & 1;              // this wave's dW fragment
+    f32x4_t acc_dw = zero4();
+    float db[4] = {0.f, 0.f, 0.f, 0.f};                 // joints (tid >> 5) + 8 q
+    // D rows of the NEXT tile travel in registers while this tile is processed (8 joints x 32 pixel
+    // lanes per pass: 128-byte runs of each joint's row); the global latency is off the tile's path
+    constexpr int DK = PB_MAXPX / 32;
+    float dn[4][DK];
+    auto fetch_d = [&](int r0n) {
+        MTN_UNROLL for (int q = 0; q < 4; ++q) {
+            const int j = q * 8 + (tid >> 5);
+            MTN_UNROLL for (int k = 0; k < DK; ++k) {
+                const int px = (tid & 31) + 32 * k;
+                dn[q][k] = (j < J && px < RP && r0n * OW + px < OHW) ? dh[(long)j * OHW + r0n * OW + px] : 0.f;
+            }
+        }
+    };
+    fetch_d(0);
+    // scatter state (waves 0 and 1: channel fragment nt = wid): running token gradients of source
+    // rows cur, cur + 1 for source columns mt*16 + 4*(lane>>4) + r, channel nt*16 + (lane&15)
+    f32x4_t g0[2], g1[2];
+    g0[0] = g0[1] = g1[0] = g1[1] = zero4();
+    int cur = 0;
+    T* const drow = dtok + ((long)b * (hw + 1) + 1) * DIM + c0 + wid * 16 + (lane & 15);
+    auto flush = [&](const f32x4_t* g, int sy) {
+        MTN_UNROLL for (int mt = 0; mt < 2; ++mt)
+            MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                const int sx = mt * 16 + 4 * (lane >> 4) + r;
+                if (mt < MW && sx < w) drow[(long)(sy * w + sx) * DIM] = from_f<T>(g[mt][r]);
+            }
+    };
+    for (int r0 = 0; r0 < OH; r0 += RB_) {
+        __syncthreads();                                // setup done / previous tile's MFMA phases are done with sD, sY
+        // D tile from the prefetched registers, then start the next tile's fetch
+        MTN_UNROLL for (int q = 0; q < 4; ++q) {
+            const int j = q * 8 + (tid >> 5);
+            MTN_UNROLL for (int k = 0; k < DK; ++k) {
+                const int px = (tid & 31) + 32 * k;
+                if (px < RPK) sD[j * PD + px] = from_f<T>(dn[q][k]);
+                db[q] += dn[q][k];
+            }
+        }
+        if (r0 + RB_ < OH && !(skip & 8)) fetch_d(r0 + RB_);
+        // Y rows: thread = channel x (row, source column) pairs
+        if (!(skip & 1))
+        for (int i = tid >> 5; i < RB_ * w; i += 8) {
+            const int r = i / w, sx = i - r * w, oy = r0 + r, c = tid & 31;
+            float v = 0.f;
+            if (oy < OH) {
+                const float wy = tWy[oy];
+                v = (1.f - wy) * to_f<T>(sS[(tY0[oy] * w + sx) * CC + c]) + wy * to_f<T>(sS[(tY1[oy] * w + sx) * CC + c]);
+            }
+            sYf[(r * WK4 + sx) * PYF + c] = v;
+        }
+        __syncthreads();
+        // R = relu(X Y_r): fragments (row r, 16 output columns, 16 channels)
+        if (!(skip & 1))
+        for (int f = wid; f < RB_ * (OWM / 16) * 2; f += 4) {
+            const int nt = f & 1, mt = (f >> 1) % (OWM / 16), r = (f >> 1) / (OWM / 16);
+            f32x4_t u = zero4();
+            for (int k0 = 0; k0 < WK4; k0 += 4) {
+                const float fa = Mma<float>::load(sXf + (mt * 16 + frow) * PXF + k0 + (lane >> 4));
+                const float fb = ColFrag<float, false>::load(sYf + (r * WK4 + k0) * PYF + nt * 16, PYF, lane);
+                u = Mma<float>::mma(fa, fb, u);
+            }
+            MTN_UNROLL for (int q = 0; q < 4; ++q) {
+                const int ox = mt * 16 + 4 * (lane >> 4) + q;
+                if (ox < OW) sR[(r * OW + ox) * PR + nt * 16 + (lane & 15)] = from_f<T>(u[q] > 0.f ? u[q] : 0.f);
+            }
+        }
+        for (int i = RP * CC + tid; i < RPK * CC; i += 256) sR[(i / CC) * PR + (i % CC)] = from_f<T>(0.f);   // K padding rows
+        __syncthreads();
+        if (!(skip & 2)) {
+            // dW[jt][ct] += D[jt rows][pixels] x R[pixels][ct columns]
+            for (int k0 = 0; k0 < RPK; k0 += KI) {
+                const typename Mma<T>::Frag fa = Mma<T>::load(sD + (jt * 16 + frow) * PD + k0 + fk);
+                const typename Mma<T>::Frag fb = ColFrag<T, TR>::load(sR + k0 * PR + ct * 16, PR, lane);
+                acc_dw = Mma<T>::mma(fa, fb, acc_dw);
+            }
+            // G[pixels][channels] = D^T x W, masked by R > 0  (accumulator: row = pixel, column = channel)
+            for (int f = wid; f < (RPK / 16) * 2; f += 4) {
+                const int mt = f >> 1, nt = f & 1;
+                f32x4_t g = zero4();
+                MTN_UNROLL for (int k0 = 0; k0 < 32; k0 += KI) {
+                    const typename Mma<T>::Frag fa = ColFrag<T, TR>::load(sD + k0 * PD + mt * 16, PD, lane);
+                    const typename Mma<T>::Frag fb = Mma<T>::load(sW + (nt * 16 + frow) * PW + k0 + fk);
+                    g = Mma<T>::mma(fa, fb, g);
+                }
+                MTN_UNROLL for (int q = 0; q < 4; ++q) {
+                    const int px = mt * 16 + 4 * (lane >> 4) + q, cc = nt * 16 + (lane & 15);
+                    sG[px * PR + cc] = from_f<T>(to_f<T>(sR[px * PR + cc]) > 0.f ? g[q] : 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        // scatter: T_r = X^T G_r on waves 0 / 1, then the y taps into the running sums
+        if (wid < 2 && !(skip & 4))
+        for (int r = 0; r < RB_ && r0 + r < OH; ++r) {
+            const int oy = r0 + r;
+            const float wy = tWy[oy];
+            const int i0 = tY0[oy], i1 = tY1[oy];
+            if (i0 != cur) {                            // source row `cur` is complete
+                flush(g0, cur);
+                g0[0] = g1[0]; g0[1] = g1[1];
+                g1[0] = g1[1] = zero4();
+                cur = i0;
+            }
+            MTN_UNROLL for (int mt = 0; mt < 2; ++mt) {
+                if (mt < MW) {
+                    f32x4_t t = zero4();
+                    for (int k0 = 0; k0 < OWK; k0 += KI) {
+                        const typename Mma<T>::Frag fa = ColFrag<T, TR>::load(sX + k0 * PW + mt * 16, PW, lane);
+                        const typename Mma<T>::Frag fb = ColFrag<T, TR>::load(sG + (r * OW + k0) * PR + wid * 16, PR, lane);
+                        t = Mma<T>::mma(fa, fb, t);
+                    }
+                    MTN_UNROLL for (int q = 0; q < 4; ++q) {
+                        g0[mt][q] += (1.f - wy) * t[q];
+                        if (i1 != i0) g1[mt][q] += wy * t[q];
+                    }
+                }
+            }
+        }
+    }
+    if (wid < 2) {                                      // the last one or two source rows
+        flush(g0, cur);
+        if (cur + 1 < h) flush(g1, cur + 1);
+    }
+    float* row = slab + (long)b * J * (DIM + 1);
+    MTN_UNROLL for (int r = 0; r < 4; ++r) {            // accumulator: row = joint, column = channel
+        const int j = jt * 16 + 4 * (lane >> 4) + r;
+        if (j < J) row[j * DIM + c0 + ct * 16 + (lane & 15)] = acc_dw[r];
+    }
+    if (do_bias) {
+        MTN_UNROLL for (int q = 0; q < 4; ++q) {
+            float v = db[q];
+            MTN_UNROLL for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);   // the 32 pixel lanes of a joint
+            const int j = q * 8 + (tid >> 5);
+            if ((tid & 31) == 0 && j < J) row[J * DIM + j] = v;
+        }
+    }
+}
+
 // ---- loss ------------------------------------------------------------------------------------------
 // dhm = w^2 (p - t) / n ; partial[block] = sum 0.5 (w (p - t))^2 / n,  n = B*J*HW
 __global__ __launch_bounds__(256) void jmse_kernel(const float* __restrict__ hm, const float* __restrict__ tgt,
@@ -358,13 +595,46 @@ static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, vo
     return mtn_check_launch("pose_bwd");
 }
 
-void mtn_pose_set_dbg(int) {}
+static int g_pose_mma = 1;      // debug key 2: 1 selects the VALU backward kernel;
+static int g_pose_skip = 0;     // 2 * bits: timing ablations of the MFMA kernel (1 interpolation, 2 MFMA, 4 scatter, 8 prefetch)
+void mtn_pose_set_dbg(int v) { g_pose_mma = v == 1 ? 0 : 1; g_pose_skip = v > 1 ? v >> 1 : 0; }
+
+// rows of the heat map per streamed tile
+static int pose_bwd_rb(int h, int w) {
+    int rb = PB_MAXPX / (4 * w);
+    if (rb > 4 * h) rb = 4 * h;
+    return rb > PB_MAXRB ? PB_MAXRB : rb;
+}
+
+// LDS bytes of the MFMA backward for an h x w token map, or 0 when it does not apply
+template <class T>
+static size_t pose_bwd_mma_lds(int h, int w) {
+    if (4 * w > PB_MAXPX || w > 32) return 0;
+    const size_t bytes = pose_bwd_mma_bytes<T>(h, w, pose_bwd_rb(h, w));
+    return bytes <= 160 * 1024 ? bytes : 0;
+}
+
+template <class T>
+static int pose_bwd_mma_launch(const void* tok, const float* W, const float* dhm, void* dtok, float* slab, int B, int h, int w,
+                               int J, size_t lds, hipStream_t stream) {
+#ifndef MTN_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_bwd_mma_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    MTN_LAUNCH((pose_bwd_mma_kernel<T>), dim3((DIM / PB_CC) * B), dim3(256), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, w, J,
+               pose_bwd_rb(h, w), g_pose_skip);
+    return mtn_check_launch("pose_bwd");
+}
 
 int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                      int dtype, int B, int h, int w, int J, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
-    int rc;       // 16-channel chunks: ~48 KB of LDS at 12x12 tokens -> 3 workgroups per CU hide the LDS latency
-    if (J == 21) {      // hagrid.yaml: num_joints = 21 -> fully unrolled joint loops
+    int rc;
+    const size_t mma_lds = !g_pose_mma ? 0 : (dtype == MTN_BF16 ? pose_bwd_mma_lds<bf16_t>(h, w) : pose_bwd_mma_lds<float>(h, w));
+    if (mma_lds) {
+        if (dtype == MTN_BF16) rc = pose_bwd_mma_launch<bf16_t>(tok, W, dhm, dtok, slab, B, h, w, J, mma_lds, stream);
+        else rc = pose_bwd_mma_launch<float>(tok, W, dhm, dtok, slab, B, h, w, J, mma_lds, stream);
+    } else if (J == 21) {      // hagrid.yaml: num_joints = 21 -> fully unrolled joint loops
+        // VALU kernel, 16-channel chunks: ~48 KB of LDS at 12x12 tokens -> 3 workgroups per CU
         if (dtype == MTN_BF16) rc = pose_bwd_launch<bf16_t, 16, 21>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
         else rc = pose_bwd_launch<float, 16, 21>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
     } else {

@@ -166,8 +166,19 @@ def test_pose_head(be, dtype, cfg):
     ops.pose_head_bwd(td, Wd, dhm.to(d), dtok, dwb, slab, h, w)
     be.sync()
     dW, db = dwb[:J * 256].view(J, 256), dwb[J * 256:]
-    assert rel_err(dtok.float()[:, 1:], tr.grad[:, 1:]) < tol(dtype, 1e-4, 1e-2)
-    assert rel_err(dW, Wr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    got, want = dtok.float()[:, 1:].cpu(), tr.grad[:, 1:]
+    if dtype == torch.float32:
+        assert rel_err(got, want) < 1e-4
+    else:
+        # bf16 storage: norm-wise 1e-2.  The ReLU mask is the sign of the interpolated feature, which
+        # the kernel sums in a different order than ATen (x taps on MFMA after the y mix): a feature
+        # within ~1e-7 of zero may land on the other side, which moves single elements by O(|G|);
+        # allow 0.02 % of such elements instead of a max-norm bound.
+        assert float((got - want).norm() / want.norm()) < 1e-2
+        bad = ((got - want).abs() > 1e-2 * want.abs().max()).sum().item()
+        assert bad <= max(4, got.numel() // 5000), bad      # each flipped pixel touches up to 4 token cells
+    # dW contracts T-typed operands on MFMA (bf16 mode rounds d and relu(u) like every wgrad); dbias is f32
+    assert rel_err(dW, Wr.grad) < tol(dtype, 1e-4, 1e-2) and rel_err(db, br.grad) < 1e-4
 
 
 def test_loss(be):

@@ -118,10 +118,11 @@ def main():
         dtok = torch.empty_like(tok)
         dwb = torch.empty(J * 257, device=dev)
         slab = torch.empty(ops.slab_rows(B), J * 257, device=dev)
-        for dbg in (0, 1, 2, 3):
+        for dbg, what in ((0, "MFMA kernel"), (1, "VALU kernel"), (2, "MFMA - interpolation"), (4, "MFMA - mfma phases"),
+                          (8, "MFMA - scatter"), (16, "MFMA - prefetch"), (30, "MFMA skeleton (loads + syncs only)")):
             lib.call("mtn_debug_set", 2, dbg)
             t = timeit(lambda: ops.pose_head_bwd(tok, Wp, dhm, dtok, dwb, slab, h, w))
-            print(f"pose_bwd dbg={dbg} (1: no atomics, 2: no joint loop)  {t*1e6:9.1f} us")
+            print(f"pose_bwd {what:36s} {t*1e6:9.1f} us")
         lib.call("mtn_debug_set", 2, 0)
     # ViT linears: M = B*145
     M = B * 145
