@@ -37,7 +37,7 @@ __device__ unsigned g_zero_page[64];
 // In-kernel phase stamps (diagnostic builds only: make hip EXTRA=-DMTN_STAMPS; the shipped library
 // has none).  Wave 0 of the first 256 workgroups sums the cycles of each phase of its K loop.
 #ifdef MTN_STAMPS
-__device__ unsigned long long g_stamps[256 * 8];
+__device__ unsigned long long g_stamps[256 * 16];
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(var)
@@ -110,6 +110,7 @@ void igemm_kernel(IgemmArgs p) {
     T* const sZero = sWin + CS * WR8 * BK;
     CT* const sC = reinterpret_cast<CT*>(smem);                     // [BM][CP] (after the K loop)
 
+    STAMP(st_entry);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -123,7 +124,10 @@ void igemm_kernel(IgemmArgs p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    // (multiply-high divisions throughout the prologue: a runtime integer division is ~25
+    // instructions and the prologue of a short-K tile is a fifth of its lifetime)
+    const int tile_m = tiles_n == 1 ? bid : (int)__umulhi((unsigned)bid, p.magic_tn);
+    const int tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
@@ -139,16 +143,21 @@ void igemm_kernel(IgemmArgs p) {
     // (exact for operands < 2^16, host-checked), which removes ~6 integer divisions per row from
     // both the loader prologue and the epilogue.
     const int dW_ = p.pm ? (p.OW >> 1) : p.OW, dH_ = p.pm ? (p.OH >> 1) : p.OH;
-    int q0, b0, y0, x0;
+    int q0 = 0, b0, y0, x0;
     {
-        const int per = p.B * dH_ * dW_;
-        q0 = p.pm ? m0 / per : 0;
-        const int r = m0 - q0 * per;
-        b0 = r / (dH_ * dW_);
-        const int rr = r - b0 * dH_ * dW_;
-        y0 = rr / dW_;
-        x0 = rr - y0 * dW_;
+        int r = m0;
+        if (p.pm) {
+            const int per = p.B * dH_ * dW_;
+            q0 = (r >= per) + (r >= 2 * per) + (r >= 3 * per);
+            r -= q0 * per;
+        }
+        const unsigned yt = dW_ == 1 ? (unsigned)r : __umulhi((unsigned)r, p.magic_w);        // r / dW_
+        x0 = r - (int)yt * dW_;
+        b0 = dH_ == 1 ? (int)yt : (int)__umulhi(yt, p.magic_h);                                // yt / dH_
+        y0 = (int)yt - b0 * dH_;
     }
+    // 1x1 taps at stride 1 read input pixel m itself: no decode, no padding
+    const bool pointwise = p.KH * p.KW == 1 && p.mul == 1 && p.off == 0 && p.div == 1 && !p.pm;
     auto decode = [&](int m, int& b, int& oy, int& ox) {
         const unsigned xt = (unsigned)(x0 + (m - m0));
         const unsigned yi = dW_ == 1 ? xt : __umulhi(xt, p.magic_w);       // xt / dW_
@@ -180,7 +189,9 @@ void igemm_kernel(IgemmArgs p) {
     unsigned my_taps = 0;
     MTN_UNROLL for (int i = 0; i < RA; ++i) {
         const int m = m0 + row0 + i * rstep_a;
-        if (!WIN && m < p.M) {
+        if (!WIN && pointwise && m < p.M) {
+            a_y[i] = 0; a_x[i] = 0; a_base[i] = m; a_vy[i] = 1u; a_vx[i] = 1u;
+        } else if (!WIN && m < p.M) {
             int b, oy, ox;
             decode(m, b, oy, ox);
             a_y[i] = oy * p.mul + p.off;
@@ -188,18 +199,15 @@ void igemm_kernel(IgemmArgs p) {
             a_base[i] = b * p.H * p.W;
             // validity is separable: tap (kh, kw) is readable iff its row kh and its column kw are
             unsigned vy = 0, vx = 0;
-            for (int t = 0; t < p.KH; ++t) {
-                const int ty = a_y[i] + t * p.sgn;
-                if (ty >= 0 && (ty & dmask) == 0 && (ty >> dshift) < p.H) vy |= 1u << t;
-            }
-            for (int t = 0; t < p.KW; ++t) {
-                const int tx = a_x[i] + t * p.sgn;
-                if (tx >= 0 && (tx & dmask) == 0 && (tx >> dshift) < p.W) vx |= 1u << t;
+            MTN_UNROLL for (int t = 0; t < 3; ++t) {
+                const int ty = a_y[i] + t * p.sgn, tx = a_x[i] + t * p.sgn;
+                if (t < p.KH && ty >= 0 && (ty & dmask) == 0 && (ty >> dshift) < p.H) vy |= 1u << t;
+                if (t < p.KW && tx >= 0 && (tx & dmask) == 0 && (tx >> dshift) < p.W) vx |= 1u << t;
             }
             a_vy[i] = vy; a_vx[i] = vx;
             if (p.pm)
-                for (int t = 0; t < p.KH * p.KW; ++t)
-                    if (((vy >> (t / p.KW)) & (vx >> (t % p.KW))) & 1u) my_taps |= 1u << t;
+                MTN_UNROLL for (int t = 0; t < 9; ++t)
+                    if (t < p.KH * p.KW && (((vy >> (t / 3)) & (vx >> (t % 3))) & 1u)) my_taps |= 1u << t;
         } else {
             a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0; a_vy[i] = 0; a_vx[i] = 0;
         }
@@ -247,21 +255,24 @@ void igemm_kernel(IgemmArgs p) {
     };
     // LDS-DMA issue of K step kt into buffer `stage` (no registers, no LDS stores)
     const BufDesc bufA = make_buf(p.A, p.a_bytes), bufW = make_buf(p.Wp, p.w_bytes);
+    // (K steps are issued in order: the tap index / channel offset of the next one are carried,
+    // not divided out of kt every step)
+    int ld_ti = 0, ld_c0 = 0;
     auto dma_tiles = [&](int kt, int stage) {
-        const int ti = kt / spt, c0 = (kt - ti * spt) * BK;
+        const int ti = ld_ti, c0 = ld_c0;
+        ld_c0 += BK;
+        if (ld_c0 == p.Cin) { ld_c0 = 0; ++ld_ti; }
         const int tap = (int)((tap_list >> (4 * ti)) & 15ull);
         const int k0 = tap * p.Cin + c0;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         char* a = reinterpret_cast<char*>(sA + stage * BM * PITCH_E);
         char* b = reinterpret_cast<char*>(sB + stage * BN * PITCH_E);
         const int cc = c0 + chunk * VEC;
-        if (!(p.dbg == 1 && kt > 0))
         MTN_UNROLL for (int i = 0; i < RA; ++i) {
             const int iy = (a_y[i] + kh * p.sgn) >> dshift, ix = (a_x[i] + kw * p.sgn) >> dshift;
             const unsigned e = (unsigned)((a_base[i] + iy * p.W + ix) * p.lda + cc) * (unsigned)sizeof(T);
             buf_glds16(bufA, (((a_vy[i] >> kh) & (a_vx[i] >> kw)) & 1u) ? e : 0xFFFFFFF0u, a + (wid * RA + i) * 1024);
         }
-        if (!(p.dbg == 2 && kt > 0))
         MTN_UNROLL for (int i = 0; i < RB; ++i)
             buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
                        b + (wid * RB + i) * 1024);
@@ -497,6 +508,7 @@ void igemm_kernel(IgemmArgs p) {
         MTN_UNROLL for (int j = 0; j < FN; ++j)
             store4<CT>(sC + (wm * WM + i * 16 + (lane & 15)) * CP + wn * WN + j * 16 + 4 * (lane >> 4), acc[i][j]);
     __syncthreads();
+    STAMP(st_e1);
 
     T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
     T* __restrict__ gAux = reinterpret_cast<T*>(p.aux_out);
@@ -537,6 +549,7 @@ void igemm_kernel(IgemmArgs p) {
             MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += w[e]; st_q[e] += w[e] * w[e]; }
         }
     }
+    STAMP(st_e2);
     if (p.stats) {
         __syncthreads();                                   // everyone is done reading the C tile
         float* red = reinterpret_cast<float*>(smem);       // [2][TR][BN]
@@ -553,11 +566,14 @@ void igemm_kernel(IgemmArgs p) {
         }
     }
 #ifdef MTN_STAMPS
-    if (tid == 0 && blockIdx.x < 256) {
+    // p.dbg == 4: stamp the LAST 256 workgroups (steady state) instead of the first (cold start)
+    const int st_first = p.dbg == 4 ? (int)gridDim.x - 256 : 0;
+    if (tid == 0 && (int)blockIdx.x >= st_first && (int)blockIdx.x < st_first + 256) {
         const unsigned long long st_end = __builtin_amdgcn_s_memtime();
-        unsigned long long* o = g_stamps + blockIdx.x * 8;
+        unsigned long long* o = g_stamps + ((int)blockIdx.x - st_first) * 16;
         o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[2]; o[3] = st_acc[3]; o[4] = st_acc[4];
-        o[5] = st_loop_end - st_begin; o[6] = st_end - st_loop_end; o[7] = st_begin;
+        o[5] = st_loop_end - st_begin; o[6] = st_end - st_loop_end; o[7] = st_begin - st_entry;
+        o[8] = st_e1 - st_loop_end; o[9] = st_e2 - st_e1; o[10] = st_end - st_e2;
     }
 #endif
 }
@@ -605,7 +621,10 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     }
 #endif
     const int tiles = mtn_cdiv(p.M, BM) * (p.N / BN);
-    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN, STAGES>), dim3(tiles), dim3(NT), lds, stream, p);
+    IgemmArgs q = p;
+    q.magic_tn = p.N / BN > 1 ? (unsigned)(0x100000000ull / (unsigned)(p.N / BN)) + 1u : 0u;
+    MTN_REQUIRE((long)tiles * (p.N / BN) < (1L << 32), "igemm: too many tiles");
+    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN, STAGES>), dim3(tiles), dim3(NT), lds, stream, q);
     return mtn_check_launch("igemm");
 }
 
@@ -663,7 +682,7 @@ void mtn_igemm_set_tile_n64(int rows) { g_tile_n64 = rows == 256 ? 256 : 128; }
 void mtn_igemm_set_tile(int t) { g_igemm_tile = t; }
 int mtn_igemm_read_stamps(void* dst, size_t bytes) {
 #if defined(MTN_STAMPS) && !defined(MTN_EMU)
-    if (bytes > sizeof(unsigned long long) * 256 * 8) bytes = sizeof(unsigned long long) * 256 * 8;
+    if (bytes > sizeof(unsigned long long) * 256 * 16) bytes = sizeof(unsigned long long) * 256 * 16;
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 #else
     (void)dst; (void)bytes;
@@ -697,7 +716,9 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.div == 1 || p.div == 2, "igemm: div=%d", p.div);
     MTN_REQUIRE(p.KH * p.KW <= 9, "igemm: at most 9 taps");
     MTN_REQUIRE(p.OH < 32768 && p.OW < 32768, "igemm: spatial size too large for the magic row decode");
-    MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && !p.stats), "igemm: parity-major rows need even OH/OW");
+    MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && !p.stats && p.KH == 3 && p.KW == 3),
+                "igemm: parity-major rows need a 3x3 tap set and even OH/OW");
+    MTN_REQUIRE((long)p.M * (p.pm ? p.OW / 2 : p.OW) < (1L << 32), "igemm: M * OW too large for the magic row decode");
     MTN_REQUIRE(p.lda % (bk / 8) == 0 && p.ldc % (bk / 8) == 0, "igemm: lda/ldc must keep 16-byte alignment");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "igemm: M=%d != B*OH*OW", p.M);
     MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 30) && (long)p.M * p.ldc < (1L << 31) && (long)p.N * p.K < (1L << 30),

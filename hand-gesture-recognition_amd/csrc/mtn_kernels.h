@@ -25,8 +25,9 @@ struct IgemmArgs {
     float* stats;         // [tiles_m][2][N] BN partial sums, or null
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
+    unsigned magic_tn;           // filled at launch: multiply-high divisor of the tile index (N / BN)
     unsigned a_bytes, w_bytes;   // filled by mtn_igemm_run: byte extents of A / Wp (buffer descriptors)
-    int dbg;                     // timing experiments only (debug key 8): 1 = skip the A loads after step 0, 2 = skip W
+    int dbg;                     // diagnostic builds (debug key 8): 4 = stamp the last 256 workgroups instead of the first
 };
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
