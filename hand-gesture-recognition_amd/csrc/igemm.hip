@@ -30,9 +30,6 @@ namespace {
 constexpr int ROW_BYTES = 128;          // reduction bytes per row per K step
 constexpr int PITCH_BYTES = 144;        // padded LDS row (register-staged pipelines)
 
-// rows that fall into the zero padding of a convolution read this page instead (LDS-DMA cannot
-// write zeros by itself)
-__device__ unsigned g_zero_page[64];
 
 // In-kernel phase stamps (diagnostic builds only: make hip EXTRA=-DMTN_STAMPS; the shipped library
 // has none).  Wave 0 of the first 256 workgroups sums the cycles of each phase of its K loop.

@@ -42,6 +42,7 @@ struct WgradArgs {
     int M, N, K;
     int splits, rows_per_split;
     unsigned y_bytes, x_bytes;    // filled by mtn_wgrad_run: byte extents of dY / X (buffer descriptors)
+    unsigned magic_ow, magic_oh;  // filled by mtn_wgrad_run: multiply-high divisors of the pixel walk
 };
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);

@@ -19,6 +19,28 @@ static int g_wgrad_dma = 1;      // LDS-DMA pipeline (debug key 5 selects the re
 
 namespace {
 
+// pixel walk of the X loader: (image, oy, ox) of a row, advanced by a fixed number of rows per K
+// step with multiply-high divisions (exact while operand * divisor < 2^32, host-checked)
+struct PixelPos { int b, oy, ox; };
+__device__ __forceinline__ unsigned wg_div(unsigned x, int d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+__device__ __forceinline__ PixelPos pixel_of(long m, const WgradArgs& p) {
+    const unsigned yt = wg_div((unsigned)m, p.OW, p.magic_ow);
+    PixelPos q;
+    q.ox = (int)((unsigned)m - yt * (unsigned)p.OW);
+    q.b = (int)wg_div(yt, p.OH, p.magic_oh);
+    q.oy = (int)yt - q.b * p.OH;
+    return q;
+}
+__device__ __forceinline__ void pixel_advance(PixelPos& q, int rows, const WgradArgs& p) {
+    q.ox += rows;
+    const int cy = (int)wg_div((unsigned)q.ox, p.OW, p.magic_ow);
+    q.ox -= cy * p.OW;
+    q.oy += cy;
+    const int cb = (int)wg_div((unsigned)q.oy, p.OH, p.magic_oh);
+    q.oy -= cb * p.OH;
+    q.b += cb;
+}
+
 constexpr int PADB = 16;      // LDS row padding in bytes
 
 template <class T, int BN, int BC, int WGM, int WGN, bool TR>
@@ -73,16 +95,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
 
     const T* __restrict__ gY = reinterpret_cast<const T*>(p.dY);
     const T* __restrict__ gX = reinterpret_cast<const T*>(p.X);
-    const int ohw = p.OH * p.OW;
 
     // per-thread loader rows
     int yrow[RY], ycc[RY];
     MTN_UNROLL for (int i = 0; i < RY; ++i) { const int c = tid + i * NT; yrow[i] = c / CPRY; ycc[i] = c % CPRY; }
-    int xrow[RX], xcc[RX], xb[RX], xrem[RX];
+    int xrow[RX], xcc[RX];
+    PixelPos xpos[RX];
     MTN_UNROLL for (int i = 0; i < RX; ++i) {
         const int c = tid + i * NT; xrow[i] = c / CPRX; xcc[i] = c % CPRX;
-        const long m = m_begin + xrow[i];
-        xb[i] = (int)(m / ohw); xrem[i] = (int)(m - (long)xb[i] * ohw);
+        xpos[i] = pixel_of(m_begin + xrow[i], p);
     }
 
     chunk16 ry[RY], rx[RX];
@@ -94,13 +115,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
         }
         MTN_UNROLL for (int i = 0; i < RX; ++i) {
             const long m = mb + xrow[i];
-            const int oy = xrem[i] / p.OW, ox = xrem[i] - oy * p.OW;
-            const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+            const int iy = xpos[i].oy * p.stride - p.pad + kh, ix = xpos[i].ox * p.stride - p.pad + kw;
             const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            rx[i] = ok ? *reinterpret_cast<const chunk16*>(gX + ((long)(xb[i] * p.H + iy) * p.W + ix) * p.ldx + c0 + xcc[i] * VEC)
+            rx[i] = ok ? *reinterpret_cast<const chunk16*>(gX + ((long)(xpos[i].b * p.H + iy) * p.W + ix) * p.ldx + c0 + xcc[i] * VEC)
                        : zero_chunk();
-            xrem[i] += BMR;                                  // advance this row to the next step
-            while (xrem[i] >= ohw) { xrem[i] -= ohw; ++xb[i]; }
+            pixel_advance(xpos[i], BMR, p);                  // this row at the next step
         }
     };
     auto store_tiles = [&](int stage) {
@@ -236,7 +255,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     long m_end = m_begin + p.rows_per_split;
     if (m_end > p.M) m_end = p.M;
     const int steps = (int)((m_end - m_begin + BMR - 1) / BMR);
-    const int ohw = p.OH * p.OW;
 
     const BufDesc bufY = make_buf(p.dY, p.y_bytes), bufX = make_buf(p.X, p.x_bytes);
     // this lane's row / source chunk in each of its DMA instructions
@@ -245,13 +263,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
         yrow[i] = (wid * IY + i) * RPBY + lane / CPRY;
         ychunk[i] = Swz<T, BN>::fetch_chunk(yrow[i], lane % CPRY);
     }
-    int xrow[IX], xchunk[IX], xb[IX], xrem[IX];
+    int xrow[IX], xchunk[IX];
+    PixelPos xpos[IX];
     MTN_UNROLL for (int i = 0; i < IX; ++i) {
         xrow[i] = (wid * IX + i) * RPBX + lane / CPRX;
         xchunk[i] = Swz<T, BC>::fetch_chunk(xrow[i], lane % CPRX);
-        const long m = m_begin + xrow[i];
-        xb[i] = (int)(m / ohw);
-        xrem[i] = (int)(m - (long)xb[i] * ohw);
+        xpos[i] = pixel_of(m_begin + xrow[i], p);
     }
     auto dma_tiles = [&](int st, int stage) {
         const long mb = m_begin + (long)st * BMR;
@@ -264,13 +281,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
         }
         MTN_UNROLL for (int i = 0; i < IX; ++i) {
             const long m = mb + xrow[i];
-            const int oy = xrem[i] / p.OW, ox = xrem[i] - oy * p.OW;
-            const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+            const int iy = xpos[i].oy * p.stride - p.pad + kh, ix = xpos[i].ox * p.stride - p.pad + kw;
             const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const unsigned off = (unsigned)(((xb[i] * p.H + iy) * p.W + ix) * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
+            const unsigned off = (unsigned)(((xpos[i].b * p.H + iy) * p.W + ix) * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
             buf_glds16(bufX, ok ? off : 0xFFFFFFF0u, x + (wid * IX + i) * 1024);
-            xrem[i] += BMR;
-            while (xrem[i] >= ohw) { xrem[i] -= ohw; ++xb[i]; }
+            pixel_advance(xpos[i], BMR, p);
         }
     };
 
@@ -421,9 +436,13 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M,
                 "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
+    MTN_REQUIRE(((long)p.M + 128) * p.OW < (1L << 32) && ((long)p.M / p.OW + 128) * p.OH < (1L << 32),
+                "wgrad: M * OW too large for the multiply-high pixel walk");
     MTN_REQUIRE((long)p.M * p.lddy < (1L << 30) && (long)p.B * p.H * p.W * p.ldx < (1L << 30), "wgrad: tensor too large for 32-bit byte offsets");
     {
         const size_t esz = dtype == MTN_BF16 ? 2 : 4;
+        p.magic_ow = p.OW > 1 ? (unsigned)(0x100000000ull / (unsigned)p.OW) + 1u : 0u;
+        p.magic_oh = p.OH > 1 ? (unsigned)(0x100000000ull / (unsigned)p.OH) + 1u : 0u;
         p.y_bytes = (unsigned)((((size_t)p.M - 1) * p.lddy + p.N) * esz);
         p.x_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.ldx + p.Cin) * esz);
     }
