@@ -98,18 +98,31 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ 
     }
 }
 
+// Elementwise passes: a thread keeps ONE 16-byte channel chunk for all its rows (the grid stride is
+// a multiple of the chunks per row), so the per-channel constants are loaded once into registers
+// and the loop body is loads -> math -> store with nothing else on its dependency chain.
+template <int VEC> struct ChanConst {
+    float a[VEC], b[VEC];
+    __device__ __forceinline__ void load(const float* __restrict__ p, int C, int c) {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) { a[e] = p[c + e]; b[e] = p[C + c + e]; }
+    }
+};
+
 template <class T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ ss,
                                                          const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
                                                          int M, int C, int act) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const int cpr = C / VEC;
-    const long total = (long)M * cpr;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / cpr), c = (int)(idx - (long)m * cpr) * VEC;
+    const int gtid = blockIdx.x * 256 + threadIdx.x;
+    const int c = (gtid % cpr) * VEC;
+    const int rstep = gridDim.x * 256 / cpr;           // 256 % cpr == 0 (host-checked)
+    ChanConst<VEC> k;
+    k.load(ss, C, c);
+    for (int m = gtid / cpr; m < M; m += rstep) {
         float v[VEC];
         unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * ss[c + e] + ss[C + c + e];
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * k.a[e] + k.b[e];
         if (res) {
             float r[VEC];
             unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
@@ -125,14 +138,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 // dz for one 16-byte chunk; xh = xhat.  pre-activation = y*scale+shift (+res)
 template <class T, int VEC>
 __device__ __forceinline__ void bn_dz(const T* __restrict__ dout, int lddo, const T* __restrict__ y, int ldy,
-                                      const T* __restrict__ res, int ldr, const float* __restrict__ ss,
-                                      const float* __restrict__ mr, int C, int act, int m, int c, float* dz, float* xh) {
+                                      const T* __restrict__ res, int ldr, const ChanConst<VEC>& ss,
+                                      const ChanConst<VEC>& mr, int act, int m, int c, float* dz, float* xh) {
     float g[VEC], v[VEC];
     unpack<T>(*reinterpret_cast<const chunk16*>(dout + (long)m * lddo + c), g);
     unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
-    MTN_UNROLL for (int e = 0; e < VEC; ++e) xh[e] = (v[e] - mr[c + e]) * mr[C + c + e];
+    MTN_UNROLL for (int e = 0; e < VEC; ++e) xh[e] = (v[e] - mr.a[e]) * mr.b[e];
     if (act == MTN_ACT_SILU) {
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * ss[c + e] + ss[C + c + e];
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * ss.a[e] + ss.b[e];
         if (res) {
             float r[VEC];
             unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
@@ -162,11 +175,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     if (r1 > M) r1 = M;
     float s0[VEC], s1[VEC];
     MTN_UNROLL for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    ChanConst<VEC> kss, kmr;
+    if (rl < rl_n) { kss.load(ss, C, c); kmr.load(mr, C, c); }
     if (rl < rl_n)
 #pragma unroll 2
         for (int m = r0 + rl; m < r1; m += rl_n) {
             float dz[VEC], xh[VEC];
-            bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, ss, mr, C, act, m, c, dz, xh);
+            bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, kss, kmr, act, m, c, dz, xh);
             MTN_UNROLL for (int e = 0; e < VEC; ++e) { s0[e] += dz[e]; s1[e] += dz[e] * xh[e]; }
         }
     if (rl < rl_n) {
@@ -208,15 +223,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            int ldextra, int M, int C, int act) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const int cpr = C / VEC;
-    const long total = (long)M * cpr;
+    const int gtid = blockIdx.x * 256 + threadIdx.x;
+    const int c = (gtid % cpr) * VEC;
+    const int rstep = gridDim.x * 256 / cpr;
+    ChanConst<VEC> kss, kmr, kco;
+    kss.load(ss, C, c); kmr.load(mr, C, c); kco.load(coef, C, c);
     // rows in DESCENDING order: the reduce pass that just ran left the tail of dout / y in the
     // memory-side cache, so the re-read starts where it still hits
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        const long idx = total - 1 - it;
-        const int m = (int)(idx / cpr), c = (int)(idx - (long)m * cpr) * VEC;
+    for (int m = M - 1 - gtid / cpr; m >= 0; m -= rstep) {
         float dz[VEC], xh[VEC], o[VEC];
-        bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, ss, mr, C, act, m, c, dz, xh);
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) o[e] = ss[c + e] * (dz[e] - coef[c + e] - xh[e] * coef[C + c + e]);
+        bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, kss, kmr, act, m, c, dz, xh);
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) o[e] = kss.a[e] * (dz[e] - kco.a[e] - xh[e] * kco.b[e]);
         *reinterpret_cast<chunk16*>(dy + (long)m * lddy + c) = pack<T>(o);
         if (dres) {          // gradient of the residual input (= dz, the pre-activation gradient)
             if (extra) {
@@ -292,6 +309,7 @@ int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res,
     const int vec = dtype == MTN_BF16 ? 8 : 4;
     MTN_REQUIRE(C % vec == 0 && ldy % vec == 0 && ldo % vec == 0 && (!res || ldr % vec == 0), "bn_act_fwd: alignment");
     MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "bn_act_fwd: act=%d", act);
+    MTN_REQUIRE(C / vec <= 256 && 256 % (C / vec) == 0, "bn_act_fwd: C=%d unsupported (16-byte chunks per row must divide 256)", C);
     const long total = (long)M * (C / vec);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_act_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16_t*)y, ldy, ss,
