@@ -304,7 +304,7 @@ int mtn_ln_fwd_run(const void* x, int ldx, const float* gamma, const float* beta
     return mtn_check_launch("ln_fwd");
 }
 
-static const int kLnRows = 64;
+static const int kLnRows = 16;     // rows per workgroup (4 per wave): 2320 workgroups at B*N = 37120 fill the chip once
 int mtn_rowslab_blocks(int M) { return mtn_cdiv(M, kLnRows); }
 
 int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma,
