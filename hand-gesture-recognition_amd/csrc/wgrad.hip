@@ -88,6 +88,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     const int kcol0 = tile_k * BC;                     // column in [0, K)
     const int tap = kcol0 / p.Cin, c0 = kcol0 - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const bool pointwise = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
     const long m_begin = (long)split * p.rows_per_split;
     long m_end = m_begin + p.rows_per_split;
     if (m_end > p.M) m_end = p.M;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     PixelPos xpos[RX];
     MTN_UNROLL for (int i = 0; i < RX; ++i) {
         const int c = tid + i * NT; xrow[i] = c / CPRX; xcc[i] = c % CPRX;
-        xpos[i] = pixel_of(m_begin + xrow[i], p);
+        xpos[i] = pointwise ? PixelPos{0, 0, 0} : pixel_of(m_begin + xrow[i], p);
     }
 
     chunk16 ry[RY], rx[RX];
@@ -115,6 +116,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
         }
         MTN_UNROLL for (int i = 0; i < RX; ++i) {
             const long m = mb + xrow[i];
+            if (pointwise) {                                 // 1x1 taps at stride 1: input pixel m itself
+                rx[i] = (m < m_end) ? *reinterpret_cast<const chunk16*>(gX + m * p.ldx + c0 + xcc[i] * VEC) : zero_chunk();
+                continue;
+            }
             const int iy = xpos[i].oy * p.stride - p.pad + kh, ix = xpos[i].ox * p.stride - p.pad + kw;
             const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             rx[i] = ok ? *reinterpret_cast<const chunk16*>(gX + ((long)(xpos[i].b * p.H + iy) * p.W + ix) * p.ldx + c0 + xcc[i] * VEC)
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     const int kcol0 = tile_k * BC;
     const int tap = kcol0 / p.Cin, c0 = kcol0 - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const bool pointwise = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
     const long m_begin = (long)split * p.rows_per_split;
     long m_end = m_begin + p.rows_per_split;
     if (m_end > p.M) m_end = p.M;
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     MTN_UNROLL for (int i = 0; i < IX; ++i) {
         xrow[i] = (wid * IX + i) * RPBX + lane / CPRX;
         xchunk[i] = Swz<T, BC>::fetch_chunk(xrow[i], lane % CPRX);
-        xpos[i] = pixel_of(m_begin + xrow[i], p);
+        xpos[i] = pointwise ? PixelPos{0, 0, 0} : pixel_of(m_begin + xrow[i], p);
     }
     auto dma_tiles = [&](int st, int stage) {
         const long mb = m_begin + (long)st * BMR;
@@ -281,6 +287,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
         }
         MTN_UNROLL for (int i = 0; i < IX; ++i) {
             const long m = mb + xrow[i];
+            if (pointwise) {                                 // 1x1 taps at stride 1: input pixel m itself
+                const unsigned off = (unsigned)(m * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
+                buf_glds16(bufX, m < m_end ? off : 0xFFFFFFF0u, x + (wid * IX + i) * 1024);
+                continue;
+            }
             const int iy = xpos[i].oy * p.stride - p.pad + kh, ix = xpos[i].ox * p.stride - p.pad + kw;
             const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const unsigned off = (unsigned)(((xpos[i].b * p.H + iy) * p.W + ix) * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
@@ -436,7 +447,8 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M,
                 "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
-    MTN_REQUIRE(((long)p.M + 128) * p.OW < (1L << 32) && ((long)p.M / p.OW + 128) * p.OH < (1L << 32),
+    MTN_REQUIRE((p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) ||
+                    (((long)p.M + 128) * p.OW < (1L << 32) && ((long)p.M / p.OW + 128) * p.OH < (1L << 32)),
                 "wgrad: M * OW too large for the multiply-high pixel walk");
     MTN_REQUIRE((long)p.M * p.lddy < (1L << 30) && (long)p.B * p.H * p.W * p.ldx < (1L << 30), "wgrad: tensor too large for 32-bit byte offsets");
     {

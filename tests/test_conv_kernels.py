@@ -166,6 +166,21 @@ def test_linear_wgrad_large_m(be, dtype):
     assert rel_err(dw, ref) < tol(dtype, 1e-4, 1e-2)
 
 
+def test_linear_wgrad_rows_beyond_2_16(be):
+    """BASELINE config 4 (384x384: 577 tokens x B=128 = 73,856 rows): the row count squared exceeds
+    2^32, which the pixel walk of the convolution path cannot index -- Linear must not go through it."""
+    if be.name == "emu":
+        pytest.skip("73,856-row operand: GPU only")
+    M, K, N = 73856, 256, 64
+    x, dy = _rand((M, K), torch.bfloat16, 16), _rand((M, N), torch.bfloat16, 17)
+    ref = dy.float().t() @ x.float()
+    ws = torch.empty(ops.linear_wgrad_workspace_bytes(torch.bfloat16, M, N, K) // 4, device=be.device)
+    dw = torch.empty((N, K), device=be.device)
+    ops.linear_wgrad(x.to(be.device), dy.to(be.device), dw, ws)
+    be.sync()
+    assert rel_err(dw, ref) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 16, 16), (3, 12, 20), (5, 32, 32)])
 def test_conv1_fwd_wgrad(be, dtype, cfg):
