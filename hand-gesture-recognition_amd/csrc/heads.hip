@@ -296,7 +296,13 @@ static size_t pose_bwd_mma_bytes(int h, int w, int rb) {
 template <class T>
 __global__ __launch_bounds__(256) void pose_bwd_mma_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                            const float* __restrict__ dhm, T* __restrict__ dtok,
-                                                           float* __restrict__ slab, int h, int w, int J, int RB_, int skip) {
+                                                           float* __restrict__ slab, int h, int w, int J, int RB_, int skip_) {
+#ifdef MTN_ABLATE          // timing ablations (tools/bench_kernels.py, diagnostic builds only): phases can be skipped
+    const int skip = skip_;
+#else
+    constexpr int skip = 0;
+    (void)skip_;
+#endif
     constexpr int CC = PB_CC;
     constexpr int PR = PoseLay<T>::PR, PD = PoseLay<T>::PD, PW = PoseLay<T>::PW;
     constexpr int KI = Mma<T>::KI;
@@ -596,7 +602,7 @@ static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, vo
 }
 
 static int g_pose_mma = 1;      // debug key 2: 1 selects the VALU backward kernel;
-static int g_pose_skip = 0;     // 2 * bits: timing ablations of the MFMA kernel (1 interpolation, 2 MFMA, 4 scatter, 8 prefetch)
+static int g_pose_skip = 0;     // 2 * bits: timing ablations of the MFMA kernel in -DMTN_ABLATE builds (1 interpolation, 2 MFMA, 4 scatter, 8 prefetch)
 void mtn_pose_set_dbg(int v) { g_pose_mma = v == 1 ? 0 : 1; g_pose_skip = v > 1 ? v >> 1 : 0; }
 
 // rows of the heat map per streamed tile

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
             MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFrag<T, TR>::load(y + ks * KI * PY + i * 16, PY, lane);
             MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = ColFrag<T, TR>::load(x + ks * KI * PX + j * 16, PX, lane);
             MTN_UNROLL for (int i = 0; i < FM; ++i)
-                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
         }
         __syncthreads();
     }
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_kernel(WgradArgs p) {
     float* __restrict__ out = p.partial + (long)split * p.N * p.K;
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j)
-            MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * WM + i * 16 + 4 * (lane >> 4) + r;
-                const int k = kcol0 + wn * WN + j * 16 + (lane & 15);
-                out[(long)n * p.K + k] = acc[i][j][r];
+            {   // the X fragment is the MFMA's row operand: a lane's quad is 4 consecutive k of one n
+                const int n = n0 + wm * WM + i * 16 + (lane & 15);
+                const int k = kcol0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                store4<float>(out + (long)n * p.K + k, acc[i][j]);
             }
 }
 
@@ -316,17 +316,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
             MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFragS<T, BN>::load(y, ks * KI, wm * WM + i * 16, lane);
             MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = ColFragS<T, BC>::load(x, ks * KI, wn * WN + j * 16, lane);
             MTN_UNROLL for (int i = 0; i < FM; ++i)
-                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
         }
         __syncthreads();
     }
     float* __restrict__ out = p.partial + (long)split * p.N * p.K;
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j)
-            MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * WM + i * 16 + 4 * (lane >> 4) + r;
-                const int k = kcol0 + wn * WN + j * 16 + (lane & 15);
-                out[(long)n * p.K + k] = acc[i][j][r];
+            {   // the X fragment is the MFMA's row operand: a lane's quad is 4 consecutive k of one n
+                const int n = n0 + wm * WM + i * 16 + (lane & 15);
+                const int k = kcol0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                store4<float>(out + (long)n * p.K + k, acc[i][j]);
             }
 }
 

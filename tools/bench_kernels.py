@@ -37,9 +37,12 @@ def main():
     ap.add_argument("--igemm_tile", type=int, default=0)
     ap.add_argument("--wgrad_tile", type=int, default=0)
     ap.add_argument("--igemm_dbg", type=int, default=0)
+    ap.add_argument("--lib", default="", help="A/B: load this build of the library instead of libmtn_hip.so")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from hand_gesture_recognition_amd import lib as _lib
+    if a.lib:
+        _lib.use_library(os.path.abspath(a.lib))
     _lib.call("mtn_debug_set", 3, a.stages)
     _lib.call("mtn_debug_set", 4, a.n64rows)
     _lib.call("mtn_debug_set", 5, a.wgrad_dma)
@@ -118,6 +121,7 @@ def main():
         dtok = torch.empty_like(tok)
         dwb = torch.empty(J * 257, device=dev)
         slab = torch.empty(ops.slab_rows(B), J * 257, device=dev)
+        # the "MFMA - phase" lines differ from the first only in a build with EXTRA=-DMTN_ABLATE
         for dbg, what in ((0, "MFMA kernel"), (1, "VALU kernel"), (2, "MFMA - interpolation"), (4, "MFMA - mfma phases"),
                           (8, "MFMA - scatter"), (16, "MFMA - prefetch"), (30, "MFMA skeleton (loads + syncs only)")):
             lib.call("mtn_debug_set", 2, dbg)
