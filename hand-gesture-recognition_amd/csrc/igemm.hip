@@ -640,6 +640,7 @@ int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
     return launch_igemm<T, BM, BN, WGM, WGN, 1>(p, stream);
 }
 
+static int g_igemm_dbg = 0;
 static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 = 64x128, 3 = 128x64 (N % 128 == 0 only)
 
 // 0: 128x128, 1: 64x128, 2: 256x64, 3: 128x64
@@ -664,6 +665,10 @@ static int igemm_config(int M, int N, int K) {
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     const int cfg = igemm_config(p.M, p.N, p.K);
+    // 128x128 runs with 8 waves (4x2, 32x64 per wave) in the default pipelines: an LDS-DMA
+    // instruction costs its wave ~100 cycles of issue, so 4 pieces per wave instead of 8 shorten the
+    // load phase of every K step (+5..7 % on these layers; the smaller tiles measured -2..4 %)
+    if (cfg == 0 && g_igemm_stages >= 3 && g_igemm_stages != 4) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
     if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
     if (cfg == 2) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
@@ -686,7 +691,6 @@ int mtn_igemm_read_stamps(void* dst, size_t bytes) {
     return 1;
 #endif
 }
-static int g_igemm_dbg = 0;
 void mtn_igemm_set_dbg(int v) { g_igemm_dbg = v; }
 
 int mtn_igemm_tiles_m(int M, int N, int K) {

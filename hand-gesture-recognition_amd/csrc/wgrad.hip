@@ -428,7 +428,9 @@ static int wgrad_dispatch(const WgradArgs& p, hipStream_t stream) {
     int bn, bc;
     wgrad_tile(p.N, p.Cin, &bn, &bc);
     if (g_wgrad_dma && (TR || sizeof(T) == 4)) {
-        if (bn == 128 && bc == 128) return launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream);
+        // 8 waves (4 DMA pieces per wave per step instead of 8: the issue of an LDS-DMA instruction
+        // costs its wave ~100 cycles); debug key 7 = 4 selects the 4-wave layout (+5..9 % slower)
+        if (bn == 128 && bc == 128) return g_wgrad_tile == 4 ? launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream) : launch_wgrad_dma<T, 128, 128, 4, 2>(p, stream);
         if (bn == 128) return launch_wgrad_dma<T, 128, 64, 4, 1>(p, stream);
         return launch_wgrad_dma<T, 64, 64, 2, 2>(p, stream);
     }
