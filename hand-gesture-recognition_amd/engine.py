@@ -36,10 +36,11 @@ class Engine:
         self.model, self.B, self.dt = model, int(batch), dtype
         self.dev = model.flat_params.device
         H, W = model.image_size
-        if H % 16 or W % 16:
-            raise ValueError("image_size must be a multiple of 16 (total stride of GELANNet)")
+        stride = model.encoder.total_stride
+        if H % stride or W % stride:
+            raise ValueError(f"image_size must be a multiple of {stride} (total stride of GELANNet)")
         self.H, self.W = H, W
-        self.fh, self.fw = H // 16, W // 16
+        self.fh, self.fw = H // stride, W // stride
         self.P = self.fh * self.fw
         self.N = self.P + 1
         self.J, self.C = model.num_joints, model.num_classes
@@ -72,13 +73,12 @@ class Engine:
         self.u_conv2 = unit(enc.conv2, H2, W2)
         self.stages = []
         h, w = self.H // 4, self.W // 4
-        for blk, down in ((enc.cspelan1, enc.down1), (enc.cspelan2, enc.down2), (enc.cspelan3, None)):
+        for blk, down in enc.stage_modules():
+            # st["branches"][j] = the residual blocks of branch j (cv2, cv3), each {"c1", "c2"} units
             st = {"C": blk.c_out, "h": h, "w": w}
             st["cv1"] = unit(blk.cv1, h, w)
-            st["b2c1"] = unit(blk.cv2[0].cv1, h, w)
-            st["b2c2"] = unit(blk.cv2[0].cv2, h, w)
-            st["b3c1"] = unit(blk.cv3[0].cv1, h, w)
-            st["b3c2"] = unit(blk.cv3[0].cv2, h, w)
+            st["branches"] = [[{"c1": unit(rb.cv1, h, w), "c2": unit(rb.cv2, h, w)} for rb in seq]
+                              for seq in (blk.cv2, blk.cv3)]
             st["cv4"] = unit(blk.cv4, h, w)
             st["down"] = unit(down, h, w) if down is not None else None
             self.stages.append(st)
@@ -162,7 +162,11 @@ class Engine:
         for st in self.stages:
             C, h, w = st["C"], st["h"], st["w"]
             st["cat"], st["g_cat"] = self._new((B, h, w, 2 * C)), self._new((B, h, w, 2 * C))
-            st["t2"], st["t3"] = self._new((B, h, w, C // 2)), self._new((B, h, w, C // 2))
+            for br in st["branches"]:
+                for i, rb in enumerate(br):
+                    rb["t"] = self._new((B, h, w, C // 2))                  # cv1 output of the block
+                    if i + 1 < len(br):                                     # output of a non-final block
+                        rb["o"], rb["g_o"] = self._new((B, h, w, C // 2)), self._new((B, h, w, C // 2))
             st["g_t"] = self._new((B, h, w, C // 2))
             st["out"], st["g_out"] = self._new((B, h, w, C)), self._new((B, h, w, C))
             if st["down"] is not None:
@@ -220,11 +224,13 @@ class Engine:
         ops.conv_fwd(x, u.wf, u.raw, u.stats if training else None, u.k, u.s)
         self._bn_fwd(u, out, training, res)
 
-    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None):
-        """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res])."""
+    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True):
+        """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res]).
+        ``dres`` receives the gradient of the residual operand, added to its old contents unless
+        ``dres_accumulate`` is False."""
         bn, dy = u.mod.bn, self._dy(u)
         ops.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
-                       dy, _ACT[u.act or res is not None], dres=dres, extra=dres)
+                       dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None)
         ops.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
         if g_in is not None:
             ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s)
@@ -243,10 +249,13 @@ class Engine:
             h2 = C // 2
             st["in"] = cur
             self._conv(st["cv1"], cur, cat[..., :C], training)                           # y0 | y1
-            self._conv(st["b2c1"], cat[..., h2:C], st["t2"], training)
-            self._conv(st["b2c2"], st["t2"], cat[..., C:C + h2], training, res=cat[..., h2:C])      # y2
-            self._conv(st["b3c1"], cat[..., C:C + h2], st["t3"], training)
-            self._conv(st["b3c2"], st["t3"], cat[..., C + h2:], training, res=cat[..., C:C + h2])   # y3
+            for j, br in enumerate(st["branches"]):                                      # y2 = cv2(y1), y3 = cv3(y2)
+                xin = cat[..., h2 * (j + 1):h2 * (j + 2)]
+                for i, rb in enumerate(br):
+                    out = cat[..., h2 * (j + 2):h2 * (j + 3)] if i + 1 == len(br) else rb["o"]
+                    self._conv(rb["c1"], xin, rb["t"], training)
+                    self._conv(rb["c2"], rb["t"], out, training, res=xin)
+                    xin = out
             self._conv(st["cv4"], cat, st["out"], training)
             cur = st["out"]
             if st["down"] is not None:
@@ -305,12 +314,20 @@ class Engine:
                 self._conv_bwd(st["down"], g_cur, st["out"], st["g_out"])
                 g_cur = st["g_out"]
             self._conv_bwd(st["cv4"], g_cur, cat, gc)
-            # branch cv3 (y3 = block(y2)): residual gradient accumulates into g_cat[y2]
-            self._conv_bwd(st["b3c2"], gc[..., C + h2:], st["t3"], st["g_t"], res=cat[..., C:C + h2], dres=gc[..., C:C + h2])
-            self._conv_bwd(st["b3c1"], st["g_t"], cat[..., C:C + h2], gc[..., C:C + h2], g_in_res=gc[..., C:C + h2])
-            # branch cv2 (y2 = block(y1))
-            self._conv_bwd(st["b2c2"], gc[..., C:C + h2], st["t2"], st["g_t"], res=cat[..., h2:C], dres=gc[..., h2:C])
-            self._conv_bwd(st["b2c1"], st["g_t"], cat[..., h2:C], gc[..., h2:C], g_in_res=gc[..., h2:C])
+            # branches in reverse (cv3: y3 = blocks(y2), then cv2: y2 = blocks(y1)), blocks in reverse.
+            # The gradient of a block's input gets the residual path (dres) and the c1 data gradient;
+            # for the first block of a branch that input is a slice of the concat, whose gradient
+            # already holds cv4's contribution (accumulate); a later block's input is private (overwrite).
+            for j in (1, 0):
+                br = st["branches"][j]
+                for i in reversed(range(len(br))):
+                    rb = br[i]
+                    g_out = gc[..., h2 * (j + 2):h2 * (j + 3)] if i + 1 == len(br) else rb["g_o"]
+                    first = i == 0
+                    xin = cat[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["o"]
+                    g_xin = gc[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["g_o"]
+                    self._conv_bwd(rb["c2"], g_out, rb["t"], st["g_t"], res=xin, dres=g_xin, dres_accumulate=first)
+                    self._conv_bwd(rb["c1"], st["g_t"], xin, g_xin, g_in_res=g_xin)
             g_in = self.g_a2 if st is self.stages[0] else self.stages[self.stages.index(st) - 1]["g_dn"]
             self._conv_bwd(st["cv1"], gc[..., :C], st["in"], g_in)
             g_cur = g_in

@@ -6,8 +6,9 @@ layer graph; the arithmetic runs in HIP kernels scheduled by ``engine.Engine``. 
 torch modules held here is ever *called*.
 
 Reference: ``autopad`` gelan.py:5-15, ``Conv`` :18-56, ``ResBasicBlock`` :59-87,
-``GELANBlock`` :124-142, ``GELANNet`` :145-176.  ``ResBottleneck`` (:90-121) is never
-instantiated by the reference's spec table (:148-151) and is not provided.
+``GELANBlock`` :124-142, ``GELANNet`` :145-176 (both spec rows, and optionally the fourth
+stage the reference keeps commented out).  ``ResBottleneck`` (:90-121) is never instantiated by
+the reference's spec table (:148-151) and is not provided.
 """
 import torch
 from torch import nn
@@ -50,36 +51,55 @@ class ResBasicBlock(nn.Module):
 
 
 class GELANBlock(nn.Module):
-    """cv1 -> chunk(2) -> cv2 -> cv3 -> cat -> cv4 (gelan.py:124-142), one block per branch."""
+    """cv1 -> chunk(2) -> cv2 -> cv3 -> cat -> cv4 (gelan.py:124-142); ``nblocks`` residual blocks per
+    branch (1 in the 'small' spec, 2 in 'large')."""
 
     def __init__(self, c_in, c_out, c_hid1, c_hid2, block=ResBasicBlock, nblocks=1):
         super().__init__()
-        if nblocks != 1 or c_hid1 // 2 != c_hid2:
-            raise NotImplementedError("only the 'small' GELAN spec (1 block per branch) is built")
+        if nblocks < 1 or c_hid1 // 2 != c_hid2:
+            raise NotImplementedError("GELANBlock needs c_hid1 // 2 == c_hid2 (all reference specs) and nblocks >= 1")
         self.cv1 = Conv(c_in, c_hid1, 1, 1)
-        self.cv2 = nn.Sequential(block(c_hid1 // 2, c_hid2))
-        self.cv3 = nn.Sequential(block(c_hid2, c_hid2))
+        self.cv2 = nn.Sequential(*([block(c_hid1 // 2, c_hid2)] + [block(c_hid2, c_hid2) for _ in range(nblocks - 1)]))
+        self.cv3 = nn.Sequential(*(block(c_hid2, c_hid2) for _ in range(nblocks)))
         self.cv4 = Conv(c_hid1 + 2 * c_hid2, c_out, 1, 1)
-        self.c_in, self.c_out, self.c_hid1, self.c_hid2 = c_in, c_out, c_hid1, c_hid2
+        self.c_in, self.c_out, self.c_hid1, self.c_hid2, self.nblocks = c_in, c_out, c_hid1, c_hid2, nblocks
 
     def forward(self, x):
         raise RuntimeError("GELANBlock runs inside the fused plan (engine.py)")
 
 
 class GELANNet(nn.Module):
-    """GELANNet('small') (gelan.py:145-176): total stride 16, 3 -> 512 channels."""
+    """GELANNet (gelan.py:145-176): 'small' = 1 block per branch, 'large' = 2 (spec table :148-151).
 
-    def __init__(self, gelan_type="small"):
+    ``stages=3`` is what the reference builds (total stride 16, 3 -> 512 channels).  ``stages=4``
+    adds the ``down3`` / ``cspelan4`` pair the reference keeps commented out (:162-163, :174-175):
+    total stride 32, still 512 channels.
+    """
+
+    SPEC = {"small": [1, 1, 1, 1], "large": [2, 2, 2, 2]}
+
+    def __init__(self, gelan_type="small", stages=3):
         super().__init__()
-        if gelan_type != "small":
-            raise NotImplementedError("MultiTaskNet hard-codes GELANNet('small') (multitasknet.py:12)")
+        if gelan_type not in self.SPEC or stages not in (3, 4):
+            raise ValueError(f"GELANNet: unknown spec {gelan_type!r} / stages={stages}")
+        layers = self.SPEC[gelan_type]
         self.conv1 = Conv(3, 64, 3, 2)
         self.conv2 = Conv(64, 128, 3, 2)
-        self.cspelan1 = GELANBlock(128, 128, 128, 64)
+        self.cspelan1 = GELANBlock(128, 128, 128, 64, ResBasicBlock, layers[0])
         self.down1 = Conv(128, 256, 3, 2)
-        self.cspelan2 = GELANBlock(256, 256, 256, 128)
+        self.cspelan2 = GELANBlock(256, 256, 256, 128, ResBasicBlock, layers[1])
         self.down2 = Conv(256, 512, 3, 2)
-        self.cspelan3 = GELANBlock(512, 512, 512, 256)
+        self.cspelan3 = GELANBlock(512, 512, 512, 256, ResBasicBlock, layers[2])
+        if stages == 4:
+            self.down3 = Conv(512, 512, 3, 2)
+            self.cspelan4 = GELANBlock(512, 512, 512, 256, ResBasicBlock, layers[3])
+        self.gelan_type, self.stages, self.total_stride = gelan_type, stages, 4 << (stages - 1)
+
+    def stage_modules(self):
+        """[(GELANBlock, following down Conv or None)] in forward order"""
+        blocks = [getattr(self, f"cspelan{i}") for i in range(1, self.stages + 1)]
+        downs = [getattr(self, f"down{i}") for i in range(1, self.stages)] + [None]
+        return list(zip(blocks, downs))
 
     def forward(self, x):
         raise RuntimeError("use MultiTaskNet (or engine.Engine.backbone_*) to run the backbone")

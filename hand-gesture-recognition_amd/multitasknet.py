@@ -49,13 +49,18 @@ class _PlanFunction(torch.autograd.Function):
 
 
 class MultiTaskNet(nn.Module):
-    def __init__(self, num_joints, num_classes, image_size, compute_dtype=None):
+    def __init__(self, num_joints, num_classes, image_size, compute_dtype=None, gelan_type="small", gelan_stages=3):
         super().__init__()
-        # identical construction order to the reference -> identical seeded default init
-        self.encoder = GELANNet("small")                                   # multitasknet.py:12
+        # identical construction order to the reference -> identical seeded default init.
+        # gelan_type / gelan_stages default to what the reference hard-codes (multitasknet.py:12);
+        # 'large' and the fourth stage are the spec rows of gelan.py:148-151,162-163 that the
+        # reference cannot reach from here.  With four stages the token
+        # grid is image_size // 32.
+        self.encoder = GELANNet(gelan_type, gelan_stages)                  # multitasknet.py:12
         self.proj = nn.Conv2d(512, 256, 1, bias=False)                     # multitasknet.py:13
+        stride = self.encoder.total_stride
         self.decoder = ViT(num_classes=num_classes, num_joints=num_joints,
-                           feature_size=[image_size[0] // 16, image_size[1] // 16],
+                           feature_size=[image_size[0] // stride, image_size[1] // stride],
                            dim=256, depth=4, heads=8, head_dim=32, mlp_dim=256)   # multitasknet.py:14-22
         self.num_joints, self.num_classes = int(num_joints), int(num_classes)
         self.image_size = (int(image_size[0]), int(image_size[1]))

@@ -10,7 +10,11 @@ Pinning: the reference holds no tests / golden vectors for this path
 (SURVEY.md section 4), so the oracle is pinned against outputs of the reference
 itself, imported on CPU in the build container by ``oracle/gen_golden.py``;
 the resulting vectors are committed under ``tests/golden/`` and
-``tests/test_oracle.py`` re-checks this file against them.
+``tests/test_oracle.py`` re-checks this file against them.  ``GELANNet('large')``
+and the non-square case are pinned the same way (``oracle/gen_golden_gelan.py``).
+The fourth GELAN stage is commented out in the reference (model/gelan.py:162-163,
+174-175): there is nothing to run it against -- parity unpinned for that one
+configuration (the blocks it is made of are the pinned ones).
 
 Every function cites the reference file:line (relative to the reference
 repository root) it follows.  The arithmetic lives in PyTorch ATen, the
@@ -87,8 +91,15 @@ def hash_normal(name: str, shape: Sequence[int], seed: int = 0) -> np.ndarray:
     return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
 
 
-def state_dict_spec(num_joints: int, num_classes: int):
+GELAN_LAYERS = {"small": [1, 1, 1, 1], "large": [2, 2, 2, 2]}      # model/gelan.py:148-151
+
+
+def state_dict_spec(num_joints: int, num_classes: int, gelan_type: str = "small", gelan_stages: int = 3):
     """The reference's state_dict layout: ordered list of (key, shape, kind).
+
+    ``gelan_type`` / ``gelan_stages`` select the other rows of the reference's spec table
+    (model/gelan.py:148-151) and the fourth stage it keeps commented out (:162-163); the defaults
+    are what ``MultiTaskNet`` hard-codes (model/multitasknet.py:12).
 
     kind in {conv, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, lin_w, lin_b, ln_w, ln_b, cls}.
     Order == ``MultiTaskNet.state_dict()`` order [SURVEY.md 8(b)];
@@ -107,18 +118,24 @@ def state_dict_spec(num_joints: int, num_classes: int):
     conv_block("encoder.conv1", 3, 64, 3)
     conv_block("encoder.conv2", 64, 128, 3)
 
-    def gelan(prefix, c_in, c_out, c_hid1, c_hid2):
+    layers = GELAN_LAYERS[gelan_type]
+
+    def gelan(prefix, c_in, c_out, c_hid1, c_hid2, nblocks):      # model/gelan.py:124-135
         conv_block(prefix + ".cv1", c_in, c_hid1, 1)
         for br, cin in (("cv2", c_hid1 // 2), ("cv3", c_hid2)):
-            conv_block(f"{prefix}.{br}.0.cv1", cin, c_hid2, 3)
-            conv_block(f"{prefix}.{br}.0.cv2", c_hid2, c_hid2, 3)
+            for i in range(nblocks):
+                conv_block(f"{prefix}.{br}.{i}.cv1", cin if i == 0 else c_hid2, c_hid2, 3)
+                conv_block(f"{prefix}.{br}.{i}.cv2", c_hid2, c_hid2, 3)
         conv_block(prefix + ".cv4", c_hid1 + 2 * c_hid2, c_out, 1)
 
-    gelan("encoder.cspelan1", 128, 128, 128, 64)
+    gelan("encoder.cspelan1", 128, 128, 128, 64, layers[0])
     conv_block("encoder.down1", 128, 256, 3)
-    gelan("encoder.cspelan2", 256, 256, 256, 128)
+    gelan("encoder.cspelan2", 256, 256, 256, 128, layers[1])
     conv_block("encoder.down2", 256, 512, 3)
-    gelan("encoder.cspelan3", 512, 512, 512, 256)
+    gelan("encoder.cspelan3", 512, 512, 512, 256, layers[2])
+    if gelan_stages == 4:
+        conv_block("encoder.down3", 512, 512, 3)
+        gelan("encoder.cspelan4", 512, 512, 512, 256, layers[3])
 
     spec.append(("proj.weight", (DIM, 512, 1, 1), "conv"))
     spec.append(("decoder.cls_token", (1, 1, DIM), "cls"))
@@ -144,8 +161,8 @@ def state_dict_spec(num_joints: int, num_classes: int):
     return spec
 
 
-def synthetic_state_dict(num_joints: int = 21, num_classes: int = 19, seed: int = 0
-                         ) -> Dict[str, Tensor]:
+def synthetic_state_dict(num_joints: int = 21, num_classes: int = 19, seed: int = 0,
+                         gelan_type: str = "small", gelan_stages: int = 3) -> Dict[str, Tensor]:
     """Deterministic weights scaled to PyTorch default-init ranges.
 
     conv / linear weights ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (kaiming-uniform a=sqrt(5));
@@ -153,7 +170,7 @@ def synthetic_state_dict(num_joints: int = 21, num_classes: int = 19, seed: int 
     affine arithmetic are exercised; running stats start at (0, 1) like nn.BatchNorm2d.
     """
     sd = {}
-    for key, shape, kind in state_dict_spec(num_joints, num_classes):
+    for key, shape, kind in state_dict_spec(num_joints, num_classes, gelan_type, gelan_stages):
         if kind in ("conv", "lin_w"):
             fan_in = int(np.prod(shape[1:]))
             w = hash_uniform(key, shape, seed) / math.sqrt(fan_in)
@@ -237,15 +254,21 @@ def res_basic_block(x: Tensor, sd, prefix: str, training: bool) -> Tensor:
 
 
 def gelan_block(x: Tensor, sd, prefix: str, training: bool) -> Tensor:
-    """``GELANBlock.forward`` (nblocks=1) -- model/gelan.py:137-142."""
+    """``GELANBlock.forward`` -- model/gelan.py:137-142; the number of residual blocks per branch
+    (``nn.Sequential`` cv2 / cv3, :127-133) is read off the state dict."""
     y = list(conv_bn_act(x, sd, prefix + ".cv1", 1, 1, True, training).chunk(2, 1))
-    y.append(res_basic_block(y[-1], sd, prefix + ".cv2.0", training))
-    y.append(res_basic_block(y[-1], sd, prefix + ".cv3.0", training))
+    for br in ("cv2", "cv3"):
+        t, i = y[-1], 0
+        while f"{prefix}.{br}.{i}.cv1.conv.weight" in sd:
+            t = res_basic_block(t, sd, f"{prefix}.{br}.{i}", training)
+            i += 1
+        y.append(t)
     return conv_bn_act(torch.cat(y, 1), sd, prefix + ".cv4", 1, 1, True, training)
 
 
 def gelan_net(x: Tensor, sd, training: bool, prefix: str = "encoder") -> Tensor:
-    """``GELANNet('small').forward`` -- model/gelan.py:165-176."""
+    """``GELANNet.forward`` -- model/gelan.py:165-176 (plus the commented-out fourth stage,
+    :174-175, when the state dict holds ``down3`` / ``cspelan4``)."""
     x = conv_bn_act(x, sd, prefix + ".conv1", 3, 2, True, training)
     x = conv_bn_act(x, sd, prefix + ".conv2", 3, 2, True, training)
     x = gelan_block(x, sd, prefix + ".cspelan1", training)
@@ -253,6 +276,9 @@ def gelan_net(x: Tensor, sd, training: bool, prefix: str = "encoder") -> Tensor:
     x = gelan_block(x, sd, prefix + ".cspelan2", training)
     x = conv_bn_act(x, sd, prefix + ".down2", 3, 2, True, training)
     x = gelan_block(x, sd, prefix + ".cspelan3", training)
+    if prefix + ".down3.conv.weight" in sd:
+        x = conv_bn_act(x, sd, prefix + ".down3", 3, 2, True, training)
+        x = gelan_block(x, sd, prefix + ".cspelan4", training)
     return x
 
 
