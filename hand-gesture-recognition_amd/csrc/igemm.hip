@@ -123,8 +123,15 @@ void igemm_kernel(IgemmArgs p) {
     }
     // (multiply-high divisions throughout the prologue: a runtime integer division is ~25
     // instructions and the prologue of a short-K tile is a fifth of its lifetime)
-    const int tile_m = tiles_n == 1 ? bid : (int)__umulhi((unsigned)bid, p.magic_tn);
+    int tile_m = tiles_n == 1 ? bid : (int)__umulhi((unsigned)bid, p.magic_tn);
     const int tile_n = bid - tile_m * tiles_n;
+    if (p.pm) {
+        // parity-major rows: the four parity classes of one image region read the same rows of the
+        // gradient; run them back to back (same XCD, adjacent in time) instead of one class sweep
+        // after the other, so those rows are fetched from HBM once instead of once per class
+        const int tm = nwg / tiles_n;
+        if ((tm & 3) == 0 && p.M == tm * BM) tile_m = (tile_m & 3) * (tm >> 2) + (tile_m >> 2);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);

@@ -111,6 +111,7 @@ def test_conv_fwd_forced_128x128_tile(be, dtype, cfg):
     (2, 4, 4, 128, 64, 1, 1),
     (3, 5, 7, 128, 128, 3, 1),
     (2, 9, 6, 64, 256, 3, 1),
+    (2, 16, 16, 64, 64, 3, 2),        # 4 x 128 rows: the parity classes' tiles are interleaved
 ])
 def test_conv_dgrad(be, stages, dtype, cfg):
     B, H, W, Cin, Cout, k, s = cfg
