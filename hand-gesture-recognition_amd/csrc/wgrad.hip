@@ -247,8 +247,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
             split = (j / tiles) * 8 + xcd;
             tile = j % tiles;
         } else {
-            split = L / tiles;
-            tile = L % tiles;
+            // many tiles per split: give each XCD group (id % 8) a contiguous range of the
+            // (split, tile) order, so the tiles of one split -- which all stream the same rows of
+            // dY and X -- share one L2 instead of spreading over all eight
+            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+            const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+            split = lin / tiles;
+            tile = lin % tiles;
         }
     }
     const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
