@@ -46,6 +46,9 @@ class Engine:
         self.J, self.C = model.num_joints, model.num_classes
         self.heads, self.hd, self.dim = 8, 32, 256
         self._bufs = {}
+        # optional callback(tag) fired inside backward() as soon as a contiguous group of parameter
+        # gradients is final: "head" (projection + decoder), ("stage", i), "stem" -- in that order
+        self.on_grads_ready = None
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -331,12 +334,14 @@ class Engine:
             g_in = self.g_a2 if st is self.stages[0] else self.stages[self.stages.index(st) - 1]["g_dn"]
             self._conv_bwd(st["cv1"], gc[..., :C], st["in"], g_in)
             g_cur = g_in
+            self._ready(("stage", self.stages.index(st)))
         self._conv_bwd(self.u_conv2, self.g_a2, self.a1, self.g_a1)
         u1, bn = self.u_conv1, self.u_conv1.mod.bn
         dy = self._dy(u1)
         ops.bn_act_bwd(self.g_a1, u1.raw, None, u1.ss, u1.mr, self.bn_part, u1.coef, self._g(bn.weight),
                        self._g(bn.bias), dy, ops.ACT_SILU)
         ops.conv1_wgrad(self.x_in, dy, self._g(u1.weight), self.conv1_part)
+        self._ready("stem")
 
     def backward(self, dlogits=None, dhm=None):
         """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
@@ -379,7 +384,12 @@ class Engine:
         gf = self.g_feat.view(self.B, self.fh, self.fw, D)
         ops.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
         ops.conv_dgrad(gf, up.wd, last["g_out"], None, 1, 1)
+        self._ready("head")
         self.backbone_backward(last["g_out"])
+
+    def _ready(self, tag):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(tag)
 
     def _pair(self, w, b):
         """Gradient slot of a (weight, bias) pair that one kernel writes as one block: the two are

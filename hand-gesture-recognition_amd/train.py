@@ -93,7 +93,7 @@ class TrainStep:
 
     def __init__(self, model: MultiTaskNet, batch_size, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.01, lr_step=(30, 40), lr_factor=0.1, process_group=None,
-                 use_graph=False, want_attn=True):
+                 use_graph=False, want_attn=True, overlap_comm=True):
         self.model, self.B = model, int(batch_size)
         self.eng = model.engine(self.B)
         self.pg = process_group
@@ -109,6 +109,15 @@ class TrainStep:
         self.use_graph, self._graph, self._static = use_graph, None, None
         if self.world > 1:
             dist.broadcast(model.flat_params, src=0, group=process_group)   # identical replicas
+        # Gradient buckets in backward order (head, stages last..first, stem): each is a contiguous
+        # slice of the flat gradient buffer and is all-reduced asynchronously the moment the engine
+        # reports it final, overlapping the reduction with the rest of the backward pass -- the
+        # parameter-heavy stages finish first, the long stage-1 backward hides their traffic.
+        self._buckets, self._works = self._bucket_ranges(model), []
+        # overlap_comm="force" runs the bucketed path on a one-rank group too (RCCL smoke test)
+        self.overlap = bool(overlap_comm) and not use_graph and (self.world > 1 or (
+            overlap_comm == "force" and dist.is_available() and dist.is_initialized()))
+        self.eng.on_grads_ready = self._bucket_ready if self.overlap else None
         model.train()
 
     # -- schedule (MultiStepLR stepped once per epoch, train.py:53-56) -----------------------------
@@ -128,9 +137,37 @@ class TrainStep:
         mdl = self.model
         ops.adamw_step(mdl.flat_params, mdl.flat_grads, self.m, self.v, self.state)
 
+    @staticmethod
+    def _bucket_ranges(model):
+        """{tag: (start, end)} over the flat gradient buffer; tags as Engine.on_grads_ready fires them."""
+        ranges, off = {}, 0
+        for name, p in model.named_parameters():
+            part = name.split(".")
+            if part[0] == "encoder" and part[1] in ("conv1", "conv2"):
+                tag = "stem"
+            elif part[0] == "encoder":
+                tag = ("stage", int(part[1][-1]) - 1)          # cspelan<k> and the down<k> that follows it
+            else:
+                tag = "head"
+            a, b = ranges.get(tag, (off, off))
+            assert b == off, f"gradient bucket {tag} is not contiguous at {name}"
+            ranges[tag] = (a, off + p.numel())
+            off += p.numel()
+        return ranges
+
+    def _bucket_ready(self, tag):
+        a, b = self._buckets[tag]
+        self._works.append(dist.all_reduce(self.model.flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
     def _sync_grads(self):
-        """One bucket: RCCL all-reduce (sum) of the flat gradient buffer; AdamW applies 1/world."""
-        if self.world > 1:
+        """RCCL all-reduce (sum) of the flat gradient buffer; AdamW applies 1/world.  With
+        ``overlap_comm`` the buckets were launched during backward and are only waited for here."""
+        if self.overlap:
+            assert len(self._works) == len(self._buckets), "a gradient bucket was never reported final"
+            for w in self._works:
+                w.wait()
+            self._works = []
+        elif self.world > 1:
             dist.all_reduce(self.model.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _eager(self, img, label, target, tw):
