@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void pose_bwd_mma_kernel(const T* __restrict__
     const int RP = RB_ * OW, RPK = (RP + 31) & ~31;     // pixels per tile, padded to whole K steps
     const int OWM = (OW + 15) & ~15, OWK = (OW + 31) & ~31, MW = (w + 15) >> 4, WK4 = (w + 3) & ~3;
     constexpr int PYF = CC + 4;                         // f32 pitches
-    const int PXF = WK4 + 4;
+    const int PXF = WK4 + 1;                            // odd pitch: the 16 rows of an A fragment land in 16 banks
     float* sYf = reinterpret_cast<float*>(smem);        // y-interpolated rows [RB][WK4 sx][PYF] f32 (sx >= w: zero)
     float* sXf = sYf + RB_ * WK4 * PYF;                 // x-interpolation matrix [OWM ox][PXF] f32 (zero padded)
     int* tY0 = reinterpret_cast<int*>(sXf + OWM * PXF); // [OH] y taps
@@ -503,6 +503,126 @@ __global__ __launch_bounds__(256) void pose_bwd_mma_kernel(const T* __restrict__
     }
 }
 
+// Forward on MFMA.  block = (image, RB output rows): for each 32-channel chunk the bilinear map is
+// one small f32 matrix product (Y_r rows by VALU straight from the tokens, then R = relu(X Y_r) on
+// the exact-f32 MFMA -- the same arithmetic as the backward, so both see the same ReLU mask), and
+// the 1x1 head accumulates hm[p][j] += R[p][c] W[j][c] over the eight chunks in registers.
+constexpr int PF_TILES = 1;          // row tiles per workgroup of the MFMA forward (4 measured 7 % slower: fewer workgroups in flight)
+template <class T>
+__global__ __launch_bounds__(256) void pose_fwd_mma_kernel(const T* __restrict__ tok, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ hm,
+                                                           int h, int w, int J, int RB_) {
+    constexpr int CC = PB_CC;
+    constexpr int PR = PoseLay<T>::PR;
+    constexpr int PWC = DIM + 16 / (int)sizeof(T);      // weight rows: all 256 channels
+    constexpr int KI = Mma<T>::KI;
+    constexpr int PYF = CC + 4;
+    MTN_DYN_SMEM(smem);
+    const int hw = h * w, OH = 4 * h, OW = 4 * w, OHW = OH * OW;
+    const int RP = RB_ * OW, RPK = (RP + 15) & ~15;
+    const int OWM = (OW + 15) & ~15, WK4 = (w + 3) & ~3, PXF = WK4 + 1;      // odd pitch: the 16 rows of an A fragment land in 16 banks
+    float* sYf = reinterpret_cast<float*>(smem);        // [RB][WK4][PYF]
+    float* sXf = sYf + RB_ * WK4 * PYF;                 // [OWM][PXF]
+    T* sR = reinterpret_cast<T*>(sXf + OWM * PXF);      // relu(u) of the chunk [MAXPX][PR]
+    T* sW = sR + PB_MAXPX * PR;                         // [32 j][PWC]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
+    for (int i = tid; i < 32 * (DIM / 4); i += 256) {   // 16-byte loads: the fill is on every workgroup's critical path
+        const int j = i / (DIM / 4), c = (i - j * (DIM / 4)) * 4;
+        f32x4_t v = zero4();
+        if (j < J) v = *reinterpret_cast<const f32x4_t*>(W + j * DIM + c);
+        store4<T>(sW + j * PWC + c, v);
+    }
+    for (int i = tid; i < OWM * PXF; i += 256) {
+        const int ox = i / PXF, sx = i - ox * PXF;
+        float v = 0.f;
+        if (ox < OW && sx < w) {
+            const Lerp l = lerp_coord(ox, w, OW);
+            v = (l.i0 == sx ? 1.f - l.w1 : 0.f) + ((l.i1 == sx && l.i1 != l.i0) ? l.w1 : 0.f);
+        }
+        sXf[i] = v;
+    }
+    for (int i = tid; i < RB_ * WK4 * PYF; i += 256) sYf[i] = 0.f;
+    const T* base = tok + ((long)b * (hw + 1) + 1) * DIM;
+    const int nfr = (RPK / 16) * 2;                     // head fragments (pixels x joints), <= 12: 3 per wave
+    // a workgroup walks PF_TILES row tiles of its image: the weight / X setup above is paid once
+    for (int tile = blockIdx.x * PF_TILES; tile < (int)(blockIdx.x + 1) * PF_TILES && tile * RB_ < OH; ++tile) {
+    const int r0 = tile * RB_;
+    f32x4_t acc[3];
+    acc[0] = acc[1] = acc[2] = zero4();
+    // this thread's (row, source column) pairs of the y mix: tap rows and weight do not depend on the chunk
+    int yo0[3], yo1[3], ydst[3];
+    float ywy[3];
+    MTN_UNROLL for (int q = 0; q < 3; ++q) {
+        const int i = (tid >> 5) + 8 * q;
+        ydst[q] = -1;
+        if (i < RB_ * w) {
+            const int r = i / w, sx = i - r * w, oy = r0 + r;
+            if (oy < OH) {
+                const Lerp l = lerp_coord(oy, h, OH);
+                yo0[q] = (l.i0 * w + sx) * DIM; yo1[q] = (l.i1 * w + sx) * DIM; ywy[q] = l.w1;
+                ydst[q] = (r * WK4 + sx) * PYF;
+            }
+        }
+    }
+    // the two token rows of each pair travel one chunk ahead in registers (global latency off the chunk's path)
+    T ta[3], tb[3];
+    auto fetch_tokens = [&](int c0) {
+        MTN_UNROLL for (int q = 0; q < 3; ++q)
+            if (ydst[q] >= 0) { ta[q] = base[yo0[q] + c0 + (tid & 31)]; tb[q] = base[yo1[q] + c0 + (tid & 31)]; }
+    };
+    fetch_tokens(0);
+    for (int c0 = 0; c0 < DIM; c0 += CC) {
+        __syncthreads();                                // setup done / the previous chunk's MFMAs are done with sYf
+        MTN_UNROLL for (int q = 0; q < 3; ++q)
+            if (ydst[q] >= 0) sYf[ydst[q] + (tid & 31)] = (1.f - ywy[q]) * to_f<T>(ta[q]) + ywy[q] * to_f<T>(tb[q]);
+        if (c0 + CC < DIM) fetch_tokens(c0 + CC);
+        __syncthreads();
+        for (int f = wid; f < RB_ * (OWM / 16) * 2; f += 4) {       // R = relu(X Y_r), exact f32
+            const int nt = f & 1, mt = (f >> 1) % (OWM / 16), r = (f >> 1) / (OWM / 16);
+            f32x4_t u = zero4();
+            for (int k0 = 0; k0 < WK4; k0 += 4) {
+                const float fa = Mma<float>::load(sXf + (mt * 16 + frow) * PXF + k0 + (lane >> 4));
+                const float fb = ColFrag<float, false>::load(sYf + (r * WK4 + k0) * PYF + nt * 16, PYF, lane);
+                u = Mma<float>::mma(fa, fb, u);
+            }
+            MTN_UNROLL for (int q = 0; q < 4; ++q) {
+                const int ox = mt * 16 + 4 * (lane >> 4) + q;
+                if (ox < OW) sR[(r * OW + ox) * PR + nt * 16 + (lane & 15)] = from_f<T>(u[q] > 0.f ? u[q] : 0.f);
+            }
+        }
+        __syncthreads();
+        MTN_UNROLL for (int q = 0; q < 3; ++q) {        // hm[pixels][joints] += R[pixels][chunk] W[joints][chunk]
+            const int f = wid + 4 * q;
+            if (f < nfr) {
+                const int mt = f >> 1, nt = f & 1;
+                MTN_UNROLL for (int k0 = 0; k0 < CC; k0 += KI) {
+                    const typename Mma<T>::Frag fa = Mma<T>::load(sR + (mt * 16 + frow) * PR + k0 + fk);
+                    const typename Mma<T>::Frag fb = Mma<T>::load(sW + (nt * 16 + frow) * PWC + c0 + k0 + fk);
+                    acc[q] = Mma<T>::mma(fa, fb, acc[q]);
+                }
+            }
+        }
+    }
+    // accumulator: row = pixel 4*(lane>>4)+r (4 consecutive pixels of one output row), column = joint
+    MTN_UNROLL for (int q = 0; q < 3; ++q) {
+        const int f = wid + 4 * q;
+        if (f < nfr) {
+            const int mt = f >> 1, j = (f & 1) * 16 + (lane & 15);
+            const int p = mt * 16 + 4 * (lane >> 4);
+            const int r = p / OW, ox = p - r * OW, oy = r0 + r;
+            if (j < J && p < RP && oy < OH) {
+                f32x4_t o = acc[q];
+                const float bj = bias[j];
+                MTN_UNROLL for (int e = 0; e < 4; ++e) o[e] += bj;
+                store4<float>(hm + ((long)(b * J + j) * OH + oy) * OW + ox, o);
+            }
+        }
+    }
+    }
+}
+
 // ---- loss ------------------------------------------------------------------------------------------
 // dhm = w^2 (p - t) / n ; partial[block] = sum 0.5 (w (p - t))^2 / n,  n = B*J*HW
 __global__ __launch_bounds__(256) void jmse_kernel(const float* __restrict__ hm, const float* __restrict__ tgt,
@@ -565,10 +685,37 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
 
 }  // namespace
 
+static int g_pose_mma = 1;      // debug key 2: 1 selects the VALU kernels
+static int pose_bwd_rb(int h, int w);
+
+template <class T>
+static size_t pose_fwd_mma_lds(int h, int w, int rb) {
+    const int OW = 4 * w, OWM = (OW + 15) & ~15, WK4 = (w + 3) & ~3;
+    return ((size_t)rb * WK4 * (PB_CC + 4) + (size_t)OWM * (WK4 + 4)) * 4 +
+           ((size_t)PB_MAXPX * PoseLay<T>::PR + 32 * (size_t)(DIM + 16 / sizeof(T))) * sizeof(T);
+}
+
 int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
                      hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_fwd: bad sizes (J=%d, max %d)", J, MAXJ);
     const int OH = 4 * h, OW = 4 * w;
+    if (g_pose_mma && 4 * w <= PB_MAXPX && w <= 32) {    // MFMA path: rows of the map as matrix products
+        const int rb = pose_bwd_rb(h, w);
+        const dim3 grid(mtn_cdiv(mtn_cdiv(OH, rb), PF_TILES), B);
+#ifndef MTN_EMU
+        static bool once_mma = false;
+        if (!once_mma) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_mma_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_mma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once_mma = true;
+        }
+#endif
+        if (dtype == MTN_BF16)
+            MTN_LAUNCH(pose_fwd_mma_kernel<bf16_t>, grid, dim3(256), pose_fwd_mma_lds<bf16_t>(h, w, rb), stream, (const bf16_t*)tok, W, bias, hm, h, w, J, rb);
+        else
+            MTN_LAUNCH(pose_fwd_mma_kernel<float>, grid, dim3(256), pose_fwd_mma_lds<float>(h, w, rb), stream, (const float*)tok, W, bias, hm, h, w, J, rb);
+        return mtn_check_launch("pose_fwd");
+    }
     const dim3 grid(mtn_cdiv(OH, TP) * mtn_cdiv(OW, TP), B);
     const size_t esz = dtype == MTN_BF16 ? 2 : 4;
     const size_t lds = (size_t)(TP * TP + 32) * (DIM * esz + 16);
@@ -601,7 +748,7 @@ static int pose_bwd_launch(const void* tok, const float* W, const float* dhm, vo
     return mtn_check_launch("pose_bwd");
 }
 
-static int g_pose_mma = 1;      // debug key 2: 1 selects the VALU backward kernel;
+// (g_pose_mma is declared above the forward launcher)
 static int g_pose_skip = 0;     // 2 * bits: timing ablations of the MFMA kernel in -DMTN_ABLATE builds (1 interpolation, 2 MFMA, 4 scatter, 8 prefetch)
 void mtn_pose_set_dbg(int v) { g_pose_mma = v == 1 ? 0 : 1; g_pose_skip = v > 1 ? v >> 1 : 0; }
 
