@@ -128,6 +128,16 @@ def main():
             t = timeit(lambda: ops.pose_head_bwd(tok, Wp, dhm, dtok, dwb, slab, h, w))
             print(f"pose_bwd {what:36s} {t*1e6:9.1f} us")
         lib.call("mtn_debug_set", 2, 0)
+    if not a.filter or "attn" in a.filter:
+        N, H, D = 145, 8, 32
+        qkv = torch.randn(B * N, 3 * H * D, device=dev).to(dt)
+        out, dout = torch.empty(B * N, H * D, device=dev, dtype=dt), torch.randn(B * N, H * D, device=dev).to(dt)
+        lse, delta = torch.empty(B * H, N, device=dev), torch.empty(B * H, N, device=dev)
+        dqkv = torch.empty_like(qkv)
+        t = timeit(lambda: ops.attention_fwd(qkv, out, lse, None, B, N, H, D, D ** -0.5))
+        print(f"attn_fwd N={N}  {t*1e6:9.1f} us  {4.0*B*H*N*N*D/t/1e12:7.1f} TF/s")
+        t = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5))
+        print(f"attn_bwd N={N}  {t*1e6:9.1f} us  {10.0*B*H*N*N*D/t/1e12:7.1f} TF/s")
     # ViT linears: M = B*145
     M = B * 145
     for name, K, N in (("qkv", 256, 768), ("out", 256, 256), ("dqkv", 768, 256)):
