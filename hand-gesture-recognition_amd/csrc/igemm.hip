@@ -219,7 +219,19 @@ void igemm_kernel(IgemmArgs p) {
     // taps that touch at least one row of this tile (workgroup-wide OR through LDS); only the
     // parity-major data gradient can skip taps, everything else runs all of them
     unsigned tile_taps = (1u << (p.KH * p.KW)) - 1u;
-    if (p.pm) {
+    const bool one_class = p.pm && (p.B * dH_ * dW_) % BM == 0;   // tiles never straddle parity classes
+    if (one_class) {
+        // the taps a parity class can hit follow from the class alone (rows at the image border
+        // only lose some of them, which their per-row masks already say): no workgroup-wide OR
+        unsigned vy = 0, vx = 0;
+        MTN_UNROLL for (int t = 0; t < 3; ++t) {
+            if ((((q0 >> 1) * p.mul + t * p.sgn + p.off) & dmask) == 0) vy |= 1u << t;
+            if ((((q0 & 1) * p.mul + t * p.sgn + p.off) & dmask) == 0) vx |= 1u << t;
+        }
+        tile_taps = 0;
+        MTN_UNROLL for (int t = 0; t < 9; ++t)
+            if (((vy >> (t / 3)) & (vx >> (t % 3))) & 1u) tile_taps |= 1u << t;
+    } else if (p.pm) {
         int* s_taps = reinterpret_cast<int*>(smem);
         if (tid == 0) *s_taps = 0;
         __syncthreads();
