@@ -74,7 +74,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
 #else
 #define MTN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(1, n)))
 #endif
-template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
+template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
 __global__ __launch_bounds__(WGM* WGN * 64) MTN_WAVES_PER_SIMD((BM * BN >= 128 * 128 ? 2 : 3))
 void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
@@ -96,6 +96,13 @@ void igemm_kernel(IgemmArgs p) {
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "loader mapping");
 
     MTN_DYN_SMEM(smem);
+    // MODE fixes the tap set at compile time (0: runtime): 1 = 1x1 taps at stride 1 in natural row
+    // order (every 1x1 conv and Linear: the tap machinery, the pixel decode and the parity-major
+    // handling fold away -- 86 instead of 780 instructions before the first load of these short-K
+    // tiles), 2 = 3x3 taps in natural row order, 3 = 3x3 taps in parity-major order.
+    constexpr bool PW = MODE == 1;
+    const int pm_ = (MODE == 1 || MODE == 2) ? 0 : (MODE == 3 ? 1 : p.pm);
+    const int KH_ = MODE == 1 ? 1 : (MODE >= 2 ? 3 : p.KH), KW_ = MODE == 1 ? 1 : (MODE >= 2 ? 3 : p.KW);
     T* const sA = reinterpret_cast<T*>(smem);                       // [NBUF][BM][PITCH_E]  (WIN: unused)
     T* const sB = WIN ? sA : sA + NBUF * BM * PITCH_E;              // [NBUF][BN][PITCH_E]
     // WIN: window rows per channel slab (multiple of 8), resident 128-byte channel slabs, their
@@ -125,7 +132,7 @@ void igemm_kernel(IgemmArgs p) {
     // instructions and the prologue of a short-K tile is a fifth of its lifetime)
     int tile_m = tiles_n == 1 ? bid : (int)__umulhi((unsigned)bid, p.magic_tn);
     const int tile_n = bid - tile_m * tiles_n;
-    if (p.pm) {
+    if (pm_) {
         // parity-major rows: the four parity classes of one image region read the same rows of the
         // gradient; run them back to back (same XCD, adjacent in time) instead of one class sweep
         // after the other, so those rows are fetched from HBM once instead of once per class
@@ -138,7 +145,7 @@ void igemm_kernel(IgemmArgs p) {
     const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wp);
 
     // ---- per-thread loader state: RA rows of A (pixel decode), RB rows of W -------------------
-    // Row order: natural (b, oy, ox), or -- for stride-2 data gradients (p.pm) -- parity-major
+    // Row order: natural (b, oy, ox), or -- for stride-2 data gradients (pm_) -- parity-major
     // (oy&1, ox&1, b, oy/2, ox/2): a tile then holds pixels of ONE parity class, for which only
     // 1, 2 or 4 of the 9 taps can hit a stored gradient, and the K loop skips the others
     // (2.25 taps on average instead of 9).  Output rows are always written at the natural index.
@@ -146,11 +153,11 @@ void igemm_kernel(IgemmArgs p) {
     // row r of the tile is then (x0 + r) carried into y and b with multiply-high "magic" divisions
     // (exact for operands < 2^16, host-checked), which removes ~6 integer divisions per row from
     // both the loader prologue and the epilogue.
-    const int dW_ = p.pm ? (p.OW >> 1) : p.OW, dH_ = p.pm ? (p.OH >> 1) : p.OH;
+    const int dW_ = pm_ ? (p.OW >> 1) : p.OW, dH_ = pm_ ? (p.OH >> 1) : p.OH;
     int q0 = 0, b0, y0, x0;
     {
         int r = m0;
-        if (p.pm) {
+        if (pm_) {
             const int per = p.B * dH_ * dW_;
             q0 = (r >= per) + (r >= 2 * per) + (r >= 3 * per);
             r -= q0 * per;
@@ -161,7 +168,7 @@ void igemm_kernel(IgemmArgs p) {
         y0 = (int)yt - b0 * dH_;
     }
     // 1x1 taps at stride 1 read input pixel m itself: no decode, no padding
-    const bool pointwise = p.KH * p.KW == 1 && p.mul == 1 && p.off == 0 && p.div == 1 && !p.pm;
+    const bool pointwise = PW || (KH_ * KW_ == 1 && p.mul == 1 && p.off == 0 && p.div == 1 && !pm_);
     auto decode = [&](int m, int& b, int& oy, int& ox) {
         const unsigned xt = (unsigned)(x0 + (m - m0));
         const unsigned yi = dW_ == 1 ? xt : __umulhi(xt, p.magic_w);       // xt / dW_
@@ -169,7 +176,7 @@ void igemm_kernel(IgemmArgs p) {
         const unsigned bi = dH_ == 1 ? yt : __umulhi(yt, p.magic_h);       // yt / dH_
         int x = (int)(xt - yi * (unsigned)dW_), y = (int)(yt - bi * (unsigned)dH_);
         b = b0 + (int)bi;
-        if (p.pm) {
+        if (pm_) {
             int q = q0;
             while (b >= p.B) { b -= p.B; ++q; }        // a tile may straddle parity classes
             oy = 2 * y + (q >> 1);
@@ -205,21 +212,21 @@ void igemm_kernel(IgemmArgs p) {
             unsigned vy = 0, vx = 0;
             MTN_UNROLL for (int t = 0; t < 3; ++t) {
                 const int ty = a_y[i] + t * p.sgn, tx = a_x[i] + t * p.sgn;
-                if (t < p.KH && ty >= 0 && (ty & dmask) == 0 && (ty >> dshift) < p.H) vy |= 1u << t;
-                if (t < p.KW && tx >= 0 && (tx & dmask) == 0 && (tx >> dshift) < p.W) vx |= 1u << t;
+                if (t < KH_ && ty >= 0 && (ty & dmask) == 0 && (ty >> dshift) < p.H) vy |= 1u << t;
+                if (t < KW_ && tx >= 0 && (tx & dmask) == 0 && (tx >> dshift) < p.W) vx |= 1u << t;
             }
             a_vy[i] = vy; a_vx[i] = vx;
-            if (p.pm)
+            if (pm_)
                 MTN_UNROLL for (int t = 0; t < 9; ++t)
-                    if (t < p.KH * p.KW && (((vy >> (t / 3)) & (vx >> (t % 3))) & 1u)) my_taps |= 1u << t;
+                    if (t < KH_ * KW_ && (((vy >> (t / 3)) & (vx >> (t % 3))) & 1u)) my_taps |= 1u << t;
         } else {
             a_y[i] = -(1 << 28); a_x[i] = -(1 << 28); a_base[i] = 0; a_vy[i] = 0; a_vx[i] = 0;
         }
     }
     // taps that touch at least one row of this tile (workgroup-wide OR through LDS); only the
     // parity-major data gradient can skip taps, everything else runs all of them
-    unsigned tile_taps = (1u << (p.KH * p.KW)) - 1u;
-    const bool one_class = p.pm && (p.B * dH_ * dW_) % BM == 0;   // tiles never straddle parity classes
+    unsigned tile_taps = (1u << (KH_ * KW_)) - 1u;
+    const bool one_class = pm_ && (p.B * dH_ * dW_) % BM == 0;   // tiles never straddle parity classes
     if (one_class) {
         // the taps a parity class can hit follow from the class alone (rows at the image border
         // only lose some of them, which their per-row masks already say): no workgroup-wide OR
@@ -231,7 +238,7 @@ void igemm_kernel(IgemmArgs p) {
         tile_taps = 0;
         MTN_UNROLL for (int t = 0; t < 9; ++t)
             if (((vy >> (t / 3)) & (vx >> (t % 3))) & 1u) tile_taps |= 1u << t;
-    } else if (p.pm) {
+    } else if (pm_) {
         int* s_taps = reinterpret_cast<int*>(smem);
         if (tid == 0) *s_taps = 0;
         __syncthreads();
@@ -251,7 +258,7 @@ void igemm_kernel(IgemmArgs p) {
         const int ti = kt / spt, c0 = (kt - ti * spt) * BK;
         const int tap = (int)((tap_list >> (4 * ti)) & 15ull);
         const int k0 = tap * p.Cin + c0;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int kh = tap / KW_, kw = tap - kh * KW_;
         MTN_UNROLL for (int i = 0; i < RA; ++i) {
             const int ty = a_y[i] + kh * p.sgn, tx = a_x[i] + kw * p.sgn;
             const int iy = ty >> dshift, ix = tx >> dshift;
@@ -280,7 +287,7 @@ void igemm_kernel(IgemmArgs p) {
         if (ld_c0 == p.Cin) { ld_c0 = 0; ++ld_ti; }
         const int tap = (int)((tap_list >> (4 * ti)) & 15ull);
         const int k0 = tap * p.Cin + c0;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int kh = tap / KW_, kw = tap - kh * KW_;
         char* a = reinterpret_cast<char*>(sA + stage * BM * PITCH_E);
         char* b = reinterpret_cast<char*>(sB + stage * BN * PITCH_E);
         const int cc = c0 + chunk * VEC;
@@ -538,7 +545,7 @@ void igemm_kernel(IgemmArgs p) {
     for (int row = trow; row < BM; row += TR) {
         int m = m0 + row;
         if (m >= p.M) continue;
-        if (p.pm) {
+        if (pm_) {
             int b, oy, ox;
             decode(m, b, oy, ox);
             m = (b * p.OH + oy) * p.OW + ox;
@@ -614,7 +621,7 @@ static bool igemm_window_ok(const IgemmArgs& p, int bm, int bn, int esz) {
            p.Cin % (cs * bk) == 0 && igemm_window_bytes(p, bm, bn, esz) <= (size_t)g_window_limit_kb * 1024;
 }
 
-template <class T, int BM, int BN, int WGM, int WGN, int STAGES>
+template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
 int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds_ab = STAGES >= 3 ? (STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
@@ -631,7 +638,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
 #ifndef MTN_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN, STAGES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGES == 5 ? 160 * 1024 : (int)lds);
         attr_set = true;
     }
@@ -640,18 +647,31 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     IgemmArgs q = p;
     q.magic_tn = p.N / BN > 1 ? (unsigned)(0x100000000ull / (unsigned)(p.N / BN)) + 1u : 0u;
     MTN_REQUIRE((long)tiles * (p.N / BN) < (1L << 32), "igemm: too many tiles");
-    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN, STAGES>), dim3(tiles), dim3(NT), lds, stream, q);
+    MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>), dim3(tiles), dim3(NT), lds, stream, q);
     return mtn_check_launch("igemm");
 }
 
 static int g_tile_n64 = 128;     // rows per tile for 64-wide outputs (debug key 4)
 static int g_igemm_stages = 5;   // window mode where it pays, LDS-DMA double buffer elsewhere
 
+// 1x1 taps at stride 1 in natural row order: every 1x1 convolution (forward and data gradient) and Linear
+static bool igemm_pointwise(const IgemmArgs& p) {
+    return p.KH * p.KW == 1 && p.mul == 1 && p.off == 0 && p.div == 1 && !p.pm;
+}
+
+// the default LDS-DMA double-buffer pipeline, specialised on the tap set
+template <class T, int BM, int BN, int WGM, int WGN>
+int launch_igemm_dma2(const IgemmArgs& p, hipStream_t stream) {
+    if (igemm_pointwise(p)) return launch_igemm<T, BM, BN, WGM, WGN, 3, 1>(p, stream);
+    if (p.KH == 3 && p.KW == 3) return p.pm ? launch_igemm<T, BM, BN, WGM, WGN, 3, 3>(p, stream) : launch_igemm<T, BM, BN, WGM, WGN, 3, 2>(p, stream);
+    return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
+}
+
 template <class T, int BM, int BN, int WGM, int WGN>
 int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
     if (g_igemm_stages == 5) {
-        if (igemm_window_ok(p, BM, BN, (int)sizeof(T))) return launch_igemm<T, BM, BN, WGM, WGN, 5>(p, stream);
-        return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
+        if (igemm_window_ok(p, BM, BN, (int)sizeof(T))) return launch_igemm<T, BM, BN, WGM, WGN, 5, 2>(p, stream);
+        return launch_igemm_dma2<T, BM, BN, WGM, WGN>(p, stream);
     }
     if (g_igemm_stages == 4) return launch_igemm<T, BM, BN, WGM, WGN, 4>(p, stream);
     if (g_igemm_stages == 3) return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
@@ -687,7 +707,8 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     // 128x128 runs with 8 waves (4x2, 32x64 per wave) in the default pipelines: an LDS-DMA
     // instruction costs its wave ~100 cycles of issue, so 4 pieces per wave instead of 8 shorten the
     // load phase of every K step (+5..7 % on these layers; the smaller tiles measured -2..4 %)
-    if (cfg == 0 && g_igemm_stages >= 3 && g_igemm_stages != 4) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
+    if (cfg == 0 && g_igemm_stages == 5) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
+    if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
     if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
     if (cfg == 2) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
