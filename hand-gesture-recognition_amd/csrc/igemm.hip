@@ -683,19 +683,21 @@ static int g_igemm_dbg = 0;
 static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 = 64x128, 3 = 128x64 (N % 128 == 0 only)
 
 // 0: 128x128, 1: 64x128, 2: 256x64, 3: 128x64
-// 128-wide outputs choose between the 128x128 tile (2 workgroups / CU = 512 slots) and the 64x128
-// tile (3 / CU = 768 slots): the short-K layers are HBM-bound and want the extra loads in flight;
-// otherwise the smaller tile is taken only where it fills the last round of workgroups clearly
-// better (measured per layer in DESIGN.md section 7b: its own main loop is ~12 % slower).
+// 128-wide outputs choose between the 128x128 tile (8 waves, 2 workgroups / CU = 512 slots) and the
+// 64x128 tile (4 waves, 3 / CU = 768 slots).  With 8 waves the larger tile wins on every layer of the
+// model (short-K ones included: +9..17 %) except where its last round of workgroups is nearly
+// empty -- 576..580 tiles on 512 slots (stage-3 3x3, proj, the 256-wide Linears): there the smaller
+// tile is 5..10 % faster (per-layer table in DESIGN.md section 7b).
 static int igemm_config(int M, int N, int K) {
+    (void)K;
     if (N % 128 == 0) {
         if (g_igemm_tile == 1) return 0;
         if (g_igemm_tile == 2) return 1;
         if (g_igemm_tile == 3) return 3;
-        if (M < 128 * 64 || K <= 256) return 1;
-        const double x128 = (double)mtn_cdiv(M, 128) * (N / 128) / 512.0, x64 = (double)mtn_cdiv(M, 64) * (N / 128) / 768.0;
-        const double e128 = x128 / (double)(long)(x128 + 0.999999), e64 = x64 / (double)(long)(x64 + 0.999999);
-        return e128 < 0.88 * e64 ? 1 : 0;
+        if (M < 128 * 64) return 1;
+        const double x128 = (double)mtn_cdiv(M, 128) * (N / 128) / 512.0;
+        const double e128 = x128 / (double)(long)(x128 + 0.999999);
+        return e128 < 0.6 ? 1 : 0;
     }
     if (g_tile_n64 == 256 && M >= 256 * 256) return 2;
     return 3;
