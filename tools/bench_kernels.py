@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--igemm_tile", type=int, default=0)
     ap.add_argument("--wgrad_tile", type=int, default=0)
     ap.add_argument("--igemm_dbg", type=int, default=0)
+    ap.add_argument("--win_limit", type=int, default=0, help="window-mode LDS limit in KB (default 53)")
     ap.add_argument("--lib", default="", help="A/B: load this build of the library instead of libmtn_hip.so")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -49,6 +50,8 @@ def main():
     _lib.call("mtn_debug_set", 6, a.igemm_tile)
     _lib.call("mtn_debug_set", 7, a.wgrad_tile)
     _lib.call("mtn_debug_set", 8, a.igemm_dbg)
+    if a.win_limit:
+        _lib.call("mtn_debug_set", 9, a.win_limit)
     dev = torch.device("cuda:0")
     B = a.batch
     esz = 2 if dt == torch.bfloat16 else 4
