@@ -93,8 +93,12 @@ def igemm_roofline(step, batch):
     # (FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes),
     # averaged over all instances of the template
     traffic, src = None, None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.startswith("r01_pmc_hbm_traffic") and name.endswith(".json"):
+    import re
+    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic.*\.json$", n)]
+    # newest collection: highest round, then highest version (r02_..._v3 > r02_..._v2 > r01_..._v10)
+    cands.sort(key=lambda n: [int(x) for x in re.findall(r"\d+", n)], reverse=True)
+    for name in cands:
+        if True:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             tot = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
             n = sum(v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
@@ -183,7 +187,7 @@ def main():
     if rank == 0:
         ips = world * a.batch * a.steps / elapsed
         out = {
-            "metric": "images/sec training step, MultiTaskNet 192x192 B=256", "value": round(ips, 1),
+            "metric": f"images/sec training step, MultiTaskNet {a.size}x{a.size} B={a.batch}", "value": round(ips, 1),
             "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",

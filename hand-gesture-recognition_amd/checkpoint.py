@@ -31,9 +31,14 @@ def save_checkpoint(path, model, epoch=0, global_step=0, extra=None):
     return path
 
 
-def load_checkpoint(path, model, map_location="cpu"):
-    """The loader of export.py:34-40: strict load of a (reference- or self-written) checkpoint."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+def load_checkpoint(path, model, map_location="cpu", trusted=False):
+    """The loader of export.py:34-40: strict load of a (reference- or self-written) checkpoint.
+
+    Files are unpickled with ``weights_only=True`` (tensors and primitives only -- what a
+    Lightning weights checkpoint holds): a third-party file cannot run code here.  A full
+    Lightning checkpoint with pickled callbacks / hyper-parameter objects needs ``trusted=True``,
+    which is the reference's own ``torch.load`` behaviour (export.py:34) and executes the pickle."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=not trusted)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     clean = OrderedDict((k[len(PREFIX):] if k.startswith(PREFIX) else k, v) for k, v in sd.items())
     model.load_state_dict(clean, strict=True)

@@ -25,11 +25,11 @@ int mtn_check_launch(const char* what) {
 extern "C" {
 
 const char* mtn_last_error(void) { return g_err; }
-int mtn_abi_version(void) { return 1; }
+int mtn_abi_version(void) { return 2; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
-int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int dtype,
+int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int stats_tiles, int dtype,
                  int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
     MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_fwd: ksize=%d", ksize);
     MTN_REQUIRE(stride == 1 || stride == 2, "conv_fwd: stride=%d", stride);
@@ -43,6 +43,7 @@ int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float*
     p.mul = stride; p.sgn = 1; p.off = -pad; p.div = 1;
     p.M = B * p.OH * p.OW; p.N = Cout; p.K = ksize * ksize * Cin;
     p.stats = stats;
+    p.stats_rows = stats_tiles;
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 

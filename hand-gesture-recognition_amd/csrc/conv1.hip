@@ -187,8 +187,8 @@ int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int 
     } else {
         const size_t lds = (size_t)PXB * (CO + 4) * 4;
 #ifndef MTN_EMU
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+        static MtnLdsAttr attr;
+        mtn_set_max_lds(attr, &conv1_fwd_kernel<float>, lds);
 #endif
         MTN_LAUNCH(conv1_fwd_kernel<float>, dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
                    W, OH, OW);

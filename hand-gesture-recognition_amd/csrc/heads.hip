@@ -652,18 +652,37 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
                                                         float* __restrict__ dlogits, const float* __restrict__ partial,
                                                         int nparts, float* __restrict__ losses, int B, int C,
                                                         float ce_weight) {
+    // A label outside [0, C) is IGNORED, the way torch's CrossEntropyLoss treats ignore_index
+    // (libs/loss.py:36 keeps the default -100): no loss, zero gradient, and the mean runs over the
+    // valid samples only (0/0 = NaN if there is none, as in torch).  Nothing is ever read or
+    // written at an index derived from such a label.
     __shared__ float red[2][256];
+    __shared__ int s_cnt[256];
+    int cnt = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const long long y = label[b];
+        cnt += (y >= 0 && y < (long long)C) ? 1 : 0;
+    }
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + st];
+        __syncthreads();
+    }
+    const float valid = (float)s_cnt[0];
     float ce = 0.f, jm = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* l = logits + (long)b * C;
+        const long long yl = label[b];
+        const bool ok = yl >= 0 && yl < (long long)C;
+        const int y = ok ? (int)yl : -1;
         float mx = l[0];
         for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
         float sum = 0.f;
         for (int c = 0; c < C; ++c) sum += __expf(l[c] - mx);
-        const int y = (int)label[b];
-        ce += mx + __logf(sum) - l[y];
+        if (ok) ce += mx + __logf(sum) - l[y];
         if (dlogits) {
-            const float k = ce_weight / (float)B, inv = 1.0f / sum;
+            const float k = ok ? ce_weight / valid : 0.f, inv = 1.0f / sum;
             for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = k * (__expf(l[c] - mx) * inv - (c == y ? 1.f : 0.f));
         }
     }
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float cl = ce_weight * red[0][0] / (float)B;
+        const float cl = ce_weight * red[0][0] / valid;
         losses[1] = cl;
         losses[2] = red[1][0];
         losses[0] = cl + red[1][0];
@@ -703,12 +722,9 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
         const int rb = pose_bwd_rb(h, w);
         const dim3 grid(mtn_cdiv(mtn_cdiv(OH, rb), PF_TILES), B);
 #ifndef MTN_EMU
-        static bool once_mma = false;
-        if (!once_mma) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_mma_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_mma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            once_mma = true;
-        }
+        static MtnLdsAttr attr_b, attr_f;
+        mtn_set_max_lds(attr_b, &pose_fwd_mma_kernel<bf16_t>, 160 * 1024);
+        mtn_set_max_lds(attr_f, &pose_fwd_mma_kernel<float>, 160 * 1024);
 #endif
         if (dtype == MTN_BF16)
             MTN_LAUNCH(pose_fwd_mma_kernel<bf16_t>, grid, dim3(256), pose_fwd_mma_lds<bf16_t>(h, w, rb), stream, (const bf16_t*)tok, W, bias, hm, h, w, J, rb);
@@ -720,12 +736,9 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     const size_t esz = dtype == MTN_BF16 ? 2 : 4;
     const size_t lds = (size_t)(TP * TP + 32) * (DIM * esz + 16);
 #ifndef MTN_EMU
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
+    static MtnLdsAttr attr_b, attr_f;
+    mtn_set_max_lds(attr_b, &pose_fwd_kernel<bf16_t>, 160 * 1024);
+    mtn_set_max_lds(attr_f, &pose_fwd_kernel<float>, 160 * 1024);
 #endif
     if (dtype == MTN_BF16)
         MTN_LAUNCH(pose_fwd_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)tok, W, bias, hm, h, w, J);
@@ -807,6 +820,9 @@ int mtn_loss_run(const float* logits, const long long* label, const float* hm, c
                  float* dlogits, float* dhm, float* partial, float* losses, int B, int C, int J, int HW, float ce_weight,
                  hipStream_t stream) {
     MTN_REQUIRE(B > 0 && C > 0 && J > 0 && HW > 0, "loss: bad sizes");
+    MTN_REQUIRE(logits && label && hm && tgt && tw && partial && losses, "loss: null operand");
+    MTN_REQUIRE((uintptr_t)label % 8 == 0 && ((uintptr_t)logits | (uintptr_t)hm | (uintptr_t)tgt | (uintptr_t)tw) % 4 == 0,
+                "loss: label must be int64-aligned, the float operands 4-byte aligned");
     const long n = (long)B * J * HW;
     const int blocks = mtn_loss_blocks(n);
     MTN_LAUNCH(jmse_kernel, dim3(blocks), dim3(256), 0, stream, hm, tgt, tw, dhm, partial, n, HW);

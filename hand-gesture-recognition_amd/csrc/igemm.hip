@@ -636,14 +636,13 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
         lds = win > rest ? win : rest;
     }
 #ifndef MTN_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, STAGES == 5 ? 160 * 1024 : (int)lds);
-        attr_set = true;
-    }
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>, STAGES == 5 ? 160 * 1024 : lds);
 #endif
     const int tiles = mtn_cdiv(p.M, BM) * (p.N / BN);
+    MTN_REQUIRE(!p.stats || p.stats_rows == mtn_cdiv(p.M, BM),
+                "igemm: the statistics slab was sized for %d row tiles, this launch writes %d (tile choice changed after "
+                "mtn_conv_stats_tiles was queried?)", p.stats_rows, mtn_cdiv(p.M, BM));
     IgemmArgs q = p;
     q.magic_tn = p.N / BN > 1 ? (unsigned)(0x100000000ull / (unsigned)(p.N / BN)) + 1u : 0u;
     MTN_REQUIRE((long)tiles * (p.N / BN) < (1L << 32), "igemm: too many tiles");

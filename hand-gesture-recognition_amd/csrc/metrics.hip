@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void pose_acc_kernel(const float* __restrict__
     }
 }
 
-// pred_label[b] = argmax_c logits[b][c] (first maximum); cm[pred][label] += 1
+// pred_label[b] = argmax_c logits[b][c] (first maximum); cm[pred][label] += 1 (a label outside
+// [0, C) is not counted: nothing is written at an index derived from it)
 __global__ __launch_bounds__(256) void cls_confusion_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
                                                             long long* __restrict__ pred_label, int* __restrict__ cm, int B,
                                                             int C) {
@@ -82,7 +83,10 @@ __global__ __launch_bounds__(256) void cls_confusion_kernel(const float* __restr
     for (int c = 1; c < C; ++c)
         if (l[c] > l[best]) best = c;
     if (pred_label) pred_label[b] = best;
-    if (cm) atomicAdd(&cm[best * C + (int)label[b]], 1);
+    if (cm) {
+        const long long y = label[b];
+        if (y >= 0 && y < (long long)C) atomicAdd(&cm[best * C + (int)y], 1);
+    }
 }
 
 // macro F1 over the labels present in predictions or targets (sklearn semantics, train.py:67-69)

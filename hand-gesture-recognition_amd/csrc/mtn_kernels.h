@@ -23,6 +23,7 @@ struct IgemmArgs {
     const void* res;      // residual [M][ldr] added after act, or null (may alias Out)
     int ldr;
     float* stats;         // [tiles_m][2][N] BN partial sums, or null
+    int stats_rows;       // rows the caller allocated for stats: must equal the tile rows of the launch
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
     unsigned magic_tn;           // filled at launch: multiply-high divisor of the tile index (N / BN)

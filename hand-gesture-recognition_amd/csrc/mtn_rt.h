@@ -21,6 +21,21 @@
 #define MTN_UNROLL _Pragma("unroll")
 #endif
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: a launch site keeps one
+// MtnLdsAttr (bit d = the attribute is set on device d), so a process that moves to another GPU
+// (model.to('cuda:1')) sets it there too instead of failing every launch that needs > 64 KB of LDS.
+#ifndef MTN_EMU
+struct MtnLdsAttr { unsigned long long done = 0; };
+template <class K>
+static inline void mtn_set_max_lds(MtnLdsAttr& st, K kern, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && ((st.done >> dev) & 1ull)) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (dev >= 0 && dev < 64) st.done |= 1ull << dev;     // (idempotent: a race between two threads only repeats the call)
+}
+#endif
+
 // status codes of the C ABI (include/mtn.h)
 #define MTN_OK 0
 #define MTN_ERR_BAD_ARG 1

@@ -360,12 +360,8 @@ int launch_wgrad(const WgradArgs& p, hipStream_t stream) {
     constexpr int BMR = 128 / (int)sizeof(T);
     constexpr size_t lds = (size_t)BMR * ((BN + BC) * sizeof(T) + 2 * PADB);
 #ifndef MTN_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BN, BC, WGM, WGN, TR>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &wgrad_kernel<T, BN, BC, WGM, WGN, TR>, lds);
 #endif
     const int tiles = (p.N / BN) * (p.K / BC);
     MTN_LAUNCH((wgrad_kernel<T, BN, BC, WGM, WGN, TR>), dim3(tiles * p.splits), dim3(NT), lds, stream, p);
@@ -378,12 +374,8 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
     constexpr int BMR = 128 / (int)sizeof(T);
     constexpr size_t lds = 2 * (size_t)BMR * (BN + BC) * sizeof(T);
 #ifndef MTN_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BN, BC, WGM, WGN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &wgrad_dma_kernel<T, BN, BC, WGM, WGN>, lds);
 #endif
     const int tiles = (p.N / BN) * (p.K / BC);
     MTN_LAUNCH((wgrad_dma_kernel<T, BN, BC, WGM, WGN>), dim3(tiles * p.splits), dim3(NT), lds, stream, p);

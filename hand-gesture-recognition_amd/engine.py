@@ -224,7 +224,7 @@ class Engine:
 
     def _conv(self, u, x, out, training, res=None):
         """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87)"""
-        ops.conv_fwd(x, u.wf, u.raw, u.stats if training else None, u.k, u.s)
+        ops.conv_fwd(x, u.wf, u.raw, u.stats if training else None, u.k, u.s, stats_tiles=u.tiles if u.bn else None)
         self._bn_fwd(u, out, training, res)
 
     def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True):
@@ -300,8 +300,15 @@ class Engine:
 
     # ---------------------------------------------------------------- loss
     def loss(self, label, target, target_weight, with_grads=True):
-        """total = 0.001*CE + JointsMSE (train.py:63-64,75); fills dlogits/dhm when with_grads."""
-        ops.loss_fwd_bwd(self.logits, label, self.hm, target, target_weight,
+        """total = 0.001*CE + JointsMSE (train.py:63-64,75); fills dlogits/dhm when with_grads.
+        The batch tensors follow libs/load.py (label int64 [B], target f32 [B,J,H/4,W/4],
+        target_weight f32 [B,J,1]); float tensors of another float dtype are converted, anything
+        else (integer labels that are not int64, wrong shapes) raises in ops.loss_fwd_bwd."""
+        if target.dtype != torch.float32 and target.is_floating_point():
+            target = target.float()
+        if target_weight.dtype != torch.float32 and target_weight.is_floating_point():
+            target_weight = target_weight.float()
+        ops.loss_fwd_bwd(self.logits, label.contiguous(), self.hm, target.contiguous(), target_weight.contiguous(),
                          self.dlogits if with_grads else None, self.dhm if with_grads else None,
                          self.loss_part, self.losses)
         return self.losses

@@ -17,7 +17,7 @@ _vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 _PROTOS = {
     "mtn_abi_version": [],
     "mtn_conv_stats_tiles": [_i, _i, _i],
-    "mtn_conv_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mtn_conv_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_linear_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_wgrad_workspace_bytes": [_i] * 8,

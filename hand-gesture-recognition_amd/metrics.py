@@ -46,8 +46,13 @@ class ClassificationMeter:
 
     def update(self, logits, label):
         logits = logits.contiguous().float()
+        if logits.dim() != 2 or logits.shape[1] != self.C:
+            raise ValueError(f"logits: expected [B,{self.C}], got {tuple(logits.shape)}")
+        if label.dtype != torch.int64 or tuple(label.shape) != (logits.shape[0],):
+            raise TypeError(f"label: expected int64 [{logits.shape[0]}], got {label.dtype} {tuple(label.shape)}")
+        label = label.contiguous()          # a label outside [0, C) is not counted (kernel guard)
         pred = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
-        lib.call("mtn_cls_confusion", logits.data_ptr(), label.contiguous().data_ptr(), pred.data_ptr(),
+        lib.call("mtn_cls_confusion", logits.data_ptr(), label.data_ptr(), pred.data_ptr(),
                  self.cm.data_ptr(), logits.shape[0], self.C, _s(logits))
         return pred
 

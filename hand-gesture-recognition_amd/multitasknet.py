@@ -15,6 +15,7 @@ Deviations from the reference module, all deliberate:
   * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode)
     or fp32 storage / exact-f32 MFMA (validation mode, the one held to 1e-3 of the reference).
 """
+import copy
 import os
 
 import torch
@@ -92,6 +93,37 @@ class MultiTaskNet(nn.Module):
         self._engines = {}
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
 
+    def _views_ok(self):
+        """True iff every parameter is still a view of ``flat_params`` at its offset and owns a
+        gradient slot (false after a deepcopy made without __deepcopy__, load_state_dict(assign=True),
+        or any code that replaced ``p.data``)."""
+        base, off = self.flat_params.data_ptr(), 0
+        for p in self.parameters():
+            if getattr(p, "_mtn_grad", None) is None or p.dtype != torch.float32 or p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return off == self.n_params
+
+    def __deepcopy__(self, memo):
+        """EMA / SWA / Lightning callbacks deep-copy the module: copy the module tree, not the
+        execution plans (GBs of activations), and give the copy its own flat buffers so that its
+        parameters alias ITS flat_params (fused AdamW / all-reduce operate on the flat buffer)."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        skip = ("flat_params", "flat_grads", "_anchor", "_engines")
+        for k, v in self.__dict__.items():
+            if k not in skip:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._engines = {}
+        new._flatten()
+        return new
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        if not self._views_ok():           # assign=True replaced the parameters: re-adopt them
+            self._flatten()
+        return out
+
     def _apply(self, fn, *args, **kwargs):
         super()._apply(fn, *args, **kwargs)       # .to() / .cuda() / .float(): params get new storage
         self._flatten()
@@ -99,6 +131,9 @@ class MultiTaskNet(nn.Module):
 
     def publish_grads(self):
         """Expose the flat gradient buffer through ``p.grad`` (views, no copies)."""
+        if not self._views_ok():
+            raise RuntimeError("MultiTaskNet parameters no longer alias flat_params (their storage was replaced after "
+                               "the plan was built); call model._flatten() and rebuild the TrainStep")
         for p in self.parameters():
             if p.grad is not p._mtn_grad:
                 p.grad = p._mtn_grad
@@ -117,6 +152,8 @@ class MultiTaskNet(nn.Module):
         key = (int(batch), self.compute_dtype)
         eng = self._engines.get(key)
         if eng is None:
+            if not self._views_ok():
+                self._flatten()
             self._engines = {key: Engine(self, batch, self.compute_dtype)}    # one live plan at a time
             eng = self._engines[key]
         return eng

@@ -41,13 +41,21 @@ def conv_stats_tiles(M, cout, K):
     return lib.call("mtn_conv_stats_tiles", M, cout, K)
 
 
-def conv_fwd(x, w, y, stats, ksize, stride):
-    """x [B,H,W,Cin] -> y [B,OH,OW,Cout] raw conv output; stats [tiles,2,Cout] f32 or None."""
+def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
+    """x [B,H,W,Cin] -> y [B,OH,OW,Cout] raw conv output; stats [>=tiles,2,Cout] f32 or None
+    (tiles = conv_stats_tiles(M, Cout, K): the slab is allocated with slab_rows(tiles) rows)."""
     B, H, W, Cin = x.shape
     Cout = y.shape[-1]
     xp, ldx = _rows(x)
     yp, ldy = _rows(y)
-    lib.call("mtn_conv_fwd", xp, ldx, w.data_ptr(), yp, ldy, _p(stats), dtype_code(x),
+    tiles = 0
+    if stats is not None:
+        # the row count the slab was SIZED for (a plan passes what it allocated; the library refuses
+        # the launch if its tile choice no longer matches)
+        tiles = conv_stats_tiles(y.numel() // Cout, Cout, ksize * ksize * Cin) if stats_tiles is None else int(stats_tiles)
+        if stats.dtype != torch.float32 or stats.numel() < tiles * 2 * Cout:
+            raise ValueError(f"conv_fwd: stats slab too small for {tiles} row tiles")
+    lib.call("mtn_conv_fwd", xp, ldx, w.data_ptr(), yp, ldy, _p(stats), tiles, dtype_code(x),
              B, H, W, Cin, Cout, ksize, stride, _stream(x))
 
 
@@ -262,10 +270,39 @@ def loss_partial_len(n):
     return lib.call("mtn_loss_partial_len", n)
 
 
+def _check(t, name, dtype, shape):
+    """The C ABI takes raw pointers: a wrong dtype / layout is an out-of-bounds device access,
+    so it is refused here (TypeError / ValueError, not an assert that -O strips)."""
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+
+
 def loss_fwd_bwd(logits, label, hm, target, target_weight, dlogits, dhm, partial, losses, ce_weight=0.001):
+    """losses[3] = (0.001*CE + JMSE, 0.001*CE, JMSE); fills dlogits / dhm when given.
+    label int64 [B] (a value outside [0, C) is ignored like torch's ignore_index), target f32 of
+    hm's shape, target_weight f32 with B*J elements ([B,J,1] or [B,J])."""
     B, C = logits.shape
     J = hm.shape[1]
     HW = hm.shape[2] * hm.shape[3]
+    _check(logits, "logits", torch.float32, (B, C))
+    _check(hm, "heatmaps", torch.float32, (B, J, hm.shape[2], hm.shape[3]))
+    _check(label, "label", torch.int64, (B,))
+    _check(target, "target", torch.float32, hm.shape)
+    if target_weight.numel() != B * J:
+        raise ValueError(f"target_weight: expected {B * J} elements ([B,J,1]), got shape {tuple(target_weight.shape)}")
+    _check(target_weight, "target_weight", torch.float32, target_weight.shape)
+    for name, t, ref in (("dlogits", dlogits, logits), ("dhm", dhm, hm)):
+        if t is not None:
+            _check(t, name, torch.float32, ref.shape)
+    if partial.dtype != torch.float32 or partial.numel() < loss_partial_len(hm.numel()) or losses.numel() < 3:
+        raise ValueError("loss workspace too small")
+    devs = {t.device for t in (logits, label, hm, target, target_weight, partial, losses)}
+    if len(devs) != 1:
+        raise ValueError(f"loss operands live on different devices: {sorted(map(str, devs))}")
     lib.call("mtn_loss_fwd_bwd", logits.data_ptr(), label.data_ptr(), hm.data_ptr(), target.data_ptr(),
              target_weight.data_ptr(), _p(dlogits), _p(dhm), partial.data_ptr(), losses.data_ptr(),
              B, C, J, HW, ce_weight, _stream(hm))

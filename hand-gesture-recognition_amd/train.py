@@ -8,8 +8,10 @@ tensors that follow the batch contract of libs/load.py (img, label, target, targ
 
 New surface (not in the reference, which is single-device): one process per GPU under
 ``torchrun``; gradients live in ONE flat fp32 buffer that is all-reduced (RCCL over xGMI, sum) in
-a single bucket; the 1/world_size mean is folded into the fused AdamW kernel.  BatchNorm
-statistics stay per GPU (no SyncBN), so DDP parity is "mean of per-rank gradients".
+five contiguous buckets launched from inside backward as each becomes final (one bucket between
+the two graphs under hipGraph replay); the 1/world_size mean is folded into the fused AdamW
+kernel.  BatchNorm statistics stay per GPU (no SyncBN), so DDP parity is "mean of per-rank
+gradients".
 """
 import argparse
 
@@ -117,7 +119,6 @@ class TrainStep:
         # overlap_comm="force" runs the bucketed path on a one-rank group too (RCCL smoke test)
         self.overlap = bool(overlap_comm) and not use_graph and (self.world > 1 or (
             overlap_comm == "force" and dist.is_available() and dist.is_initialized()))
-        self.eng.on_grads_ready = self._bucket_ready if self.overlap else None
         model.train()
 
     # -- schedule (MultiStepLR stepped once per epoch, train.py:53-56) -----------------------------
@@ -131,7 +132,15 @@ class TrainStep:
         e = self.eng
         e.forward(img, training=True, want_attn=self.want_attn)
         e.loss(label, target, tw, with_grads=True)
-        e.backward()
+        # the bucket hook lives on the (shared) engine only for the duration of THIS backward: a
+        # model(img) + loss.backward() on the same plan (validation, debugging) must not fire
+        # collectives nobody waits for
+        self._works = []
+        e.on_grads_ready = self._bucket_ready if self.overlap else None
+        try:
+            e.backward()
+        finally:
+            e.on_grads_ready = None
 
     def _update(self):
         mdl = self.model
@@ -163,7 +172,8 @@ class TrainStep:
         """RCCL all-reduce (sum) of the flat gradient buffer; AdamW applies 1/world.  With
         ``overlap_comm`` the buckets were launched during backward and are only waited for here."""
         if self.overlap:
-            assert len(self._works) == len(self._buckets), "a gradient bucket was never reported final"
+            if len(self._works) != len(self._buckets):
+                raise RuntimeError(f"{len(self._works)} of {len(self._buckets)} gradient buckets were reported final")
             for w in self._works:
                 w.wait()
             self._works = []
@@ -267,8 +277,10 @@ def build_parser():
 
 def run(args, data_cfg):
     import os
-    assert args.image_size[0] == args.image_size[1], "only square images are supported"   # train.py:191-192
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.devices != world:
+        raise SystemExit(f"--devices {args.devices} needs one process per GPU: launch with `python -m "
+                         f"torch.distributed.run --nproc-per-node {args.devices} ...` (WORLD_SIZE is {world})")
     local = int(os.environ.get("LOCAL_RANK", str(args.device)))
     torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():

@@ -44,8 +44,10 @@ int mtn_abi_version(void);
 int mtn_conv_stats_tiles(int M, int Cout, int K);
 
 /* y_raw = conv(x) (k in {1,3}, pad k/2, stride in {1,2}); w packed [Cout][k][k][Cin];
- * stats (optional) receives per-tile per-channel sum / sum-of-squares of y_raw. */
-int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats,
+ * stats (optional) receives per-tile per-channel sum / sum-of-squares of y_raw; stats_tiles is the
+ * row count the caller sized it for and must equal mtn_conv_stats_tiles(M, Cout, K) (checked:
+ * the kernel writes exactly that many rows and mtn_bn_finalize reads them). */
+int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int stats_tiles,
                  int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                  void* stream);
 

@@ -52,6 +52,20 @@ def test_classification_meter(be):
     assert np.array_equal(meter.cm.cpu().numpy(), confusion_matrix(yp, yt, labels=list(range(C))))
 
 
+def test_classification_meter_guards_labels(be):
+    C = 5
+    meter = metrics.ClassificationMeter(C, be.device)
+    logits = torch.randn(6, C, generator=torch.Generator().manual_seed(1)).to(be.device)
+    with pytest.raises(TypeError):
+        meter.update(logits, torch.zeros(6, dtype=torch.int32, device=be.device))
+    with pytest.raises(TypeError):
+        meter.update(logits, torch.zeros(5, dtype=torch.int64, device=be.device))
+    label = torch.tensor([0, 4, -1, 5, 1 << 40, 2], device=be.device)   # three labels outside [0, C)
+    meter.update(logits, label)
+    be.sync()
+    assert int(meter.cm.sum()) == 3
+
+
 def test_render_targets_and_normalize(be):
     rng = np.random.default_rng(5)
     B, J, S = 3, 21, 64

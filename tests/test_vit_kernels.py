@@ -201,6 +201,40 @@ def test_loss(be):
     assert rel_err(dl, lr.grad) < 1e-5 and rel_err(dh, hr.grad) < 1e-5
 
 
+def test_loss_rejects_bad_inputs_and_ignores_out_of_range_labels(be):
+    """The C ABI takes raw pointers: int32 labels / float64 targets / wrong shapes must be refused
+    on the host, and a label outside [0, C) is ignored like torch's ignore_index (never indexed)."""
+    B, C, J, S = 5, 19, 21, 8
+    d = be.device
+    logits, hm = _rand((B, C), torch.float32, 40).to(d), _rand((B, J, S, S), torch.float32, 41).to(d)
+    tgt = torch.rand((B, J, S, S), generator=torch.Generator().manual_seed(42)).to(d)
+    tw = torch.ones((B, J, 1), device=d)
+    label = torch.tensor([3, -100, 18, 19, 0], device=d)            # -100 and 19 are out of range
+    dl, dh = torch.empty((B, C), device=d), torch.empty((B, J, S, S), device=d)
+    part = torch.empty(ops.loss_partial_len(B * J * S * S), device=d)
+    losses = torch.empty(3, device=d)
+    with pytest.raises(TypeError):
+        ops.loss_fwd_bwd(logits, label.int(), hm, tgt, tw, dl, dh, part, losses)
+    with pytest.raises(TypeError):
+        ops.loss_fwd_bwd(logits, label, hm, tgt.double(), tw, dl, dh, part, losses)
+    with pytest.raises(ValueError):
+        ops.loss_fwd_bwd(logits, label[:-1], hm, tgt, tw, dl, dh, part, losses)
+    with pytest.raises(ValueError):
+        ops.loss_fwd_bwd(logits, label, hm, tgt[:, :-1], tw, dl, dh, part, losses)
+    with pytest.raises(ValueError):
+        ops.loss_fwd_bwd(logits, label, hm, tgt, tw[:, :-1], dl, dh, part, losses)
+    ops.loss_fwd_bwd(logits, label, hm, tgt, tw, dl, dh, part, losses, 1.0)
+    be.sync()
+    lr = logits.cpu().clone().requires_grad_(True)
+    lab = label.cpu().clone()
+    lab[lab >= C] = -100
+    ref = F.cross_entropy(lr, lab, ignore_index=-100)
+    ref.backward()
+    assert abs(float(losses[1]) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel_err(dl, lr.grad) < 1e-5
+    assert float(dl[1].abs().max()) == 0.0 and float(dl[3].abs().max()) == 0.0
+
+
 def test_adamw_and_pack(be):
     import mtn_oracle as O
     d = be.device
