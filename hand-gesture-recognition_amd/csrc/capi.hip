@@ -271,6 +271,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 7) { mtn_wgrad_set_tile(value); return MTN_OK; }
     if (key == 8) { mtn_igemm_set_dbg(value); return MTN_OK; }
     if (key == 9) { mtn_igemm_set_window_limit(value); return MTN_OK; }
+    if (key == 10) { mtn_wgrad_set_slots(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

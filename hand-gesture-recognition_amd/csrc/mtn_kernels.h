@@ -137,3 +137,4 @@ void mtn_igemm_set_dbg(int v);
 void mtn_igemm_set_window_limit(int kb);
 int mtn_igemm_read_stamps(void* dst, size_t bytes);
 void mtn_wgrad_set_tile(int t);
+void mtn_wgrad_set_slots(int n);

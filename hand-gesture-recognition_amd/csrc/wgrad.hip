@@ -16,6 +16,7 @@
 
 static int g_wgrad_tile = 0;     // debug key 7: 64 forces 64x64 tiles
 static int g_wgrad_dma = 1;      // LDS-DMA pipeline (debug key 5 selects the register-staged one)
+static int g_wgrad_slots = 0;    // debug key 10: workgroups per launch the pixel split aims at (0 = per-tile default)
 
 namespace {
 
@@ -387,6 +388,7 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
 static int g_use_tr16 = 1;
 void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
+void mtn_wgrad_set_slots(int n) { g_wgrad_slots = n > 0 ? n : 0; }
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
 
 // tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
@@ -407,6 +409,7 @@ int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_spli
     const long tiles = (long)(N / bn) * (K / bc);
     long slots = 1024;
     if (g_wgrad_dma) slots = (bn == 128 && bc == 128) ? 512 : (bn == 128 ? 768 : 1024);
+    if (g_wgrad_slots > 0) slots = g_wgrad_slots;
     long splits = slots / tiles;
     if (splits < 1) splits = 1;
     if (splits >= 8 && tiles <= 24) splits &= ~7L;        // whole splits per XCD group (see the kernel)

@@ -68,3 +68,41 @@ def test_bn_act_fwd_bwd(be, dtype, cfg):
     assert rel_err(db, br.grad) < tol(dtype, 2e-4, 2e-2)
     if with_res:
         assert rel_err(dres.float(), rr.grad + extra.float()) < tol(dtype, 1e-4, 2e-2)
+
+
+@pytest.mark.parametrize("R,C", [(700, 64), (4608, 128), (129, 72)])
+def test_bn_finalize_many_tile_rows(be, R, C):
+    """slabs of any row count (stage-1 layers write 4608 tile rows) reduce exactly (double sums)"""
+    if be.name == "emu" and R > 1000:
+        pytest.skip("large case is for the GPU")
+    g = torch.Generator().manual_seed(R)
+    count = R * 128
+    s = torch.randn(R, C, generator=g) * 10 + 3.0
+    q = torch.rand(R, C, generator=g) * 400 + 200 + s * s / 128
+    stats = torch.zeros(ops.slab_rows(R), 2, C)          # producer rows + the library's folding scratch
+    stats[:R] = torch.stack([s, q], 1)
+    d = be.device
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ss, mr = torch.empty(2, C, device=d), torch.empty(2, C, device=d)
+    rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+    ops.bn_finalize(stats.to(d), R, count, gamma.to(d), beta.to(d), rm, rv, None, ss, mr)
+    be.sync()
+    mean = s.double().sum(0) / count
+    var = (q.double().sum(0) / count - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert rel_err(mr[0], mean) < 1e-6 and rel_err(mr[1], rstd) < 1e-6
+    assert rel_err(ss[0], gamma.double() * rstd) < 1e-6
+    assert rel_err(ss[1], beta.double() - mean * gamma.double() * rstd) < 1e-5
+    assert rel_err(rv, 0.9 + 0.1 * var * count / (count - 1)) < 1e-6
+
+
+def test_bias_grad_many_slab_rows(be):
+    """the generic column sum over a slab with hundreds / thousands of rows"""
+    M = 5000 if be.name == "emu" else 37120
+    x = _rand((M, 256), torch.float32, 9)
+    d = be.device
+    part = torch.empty(ops.rowslab_rows(M), 256, device=d)
+    db = torch.empty(256, device=d)
+    ops.bias_grad(x.to(d), part, db)
+    be.sync()
+    assert rel_err(db, x.double().sum(0)) < 1e-5

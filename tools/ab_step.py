@@ -1,17 +1,27 @@
 """A/B of two builds of the library on the full training step, in ONE GPU session (boxes of the pool
-differ by several percent): python tools/ab_step.py [path/to/other/libmtn_hip.so]"""
-import sys, os, time, torch
+differ by several percent): python tools/ab_step.py [path/to/other/libmtn_hip.so] [--graph] [--key K=V ...]
+Prints the median / min of several timing windows."""
+import sys, os, time, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hand_gesture_recognition_amd import lib
-if len(sys.argv) > 1: lib.use_library(os.path.abspath(sys.argv[1]))
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+graph = "--graph" in sys.argv
+if args: lib.use_library(os.path.abspath(args[0]))
+for a in sys.argv[1:]:
+    if a.startswith("--key="):
+        k, v = a[6:].split("=")
+        lib.call("mtn_debug_set", int(k), int(v))
 from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
 from hand_gesture_recognition_amd.train import TrainStep, synthetic_batch
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 model = MultiTaskNet(21, 19, [192, 192], compute_dtype=torch.bfloat16).to(dev)
-step = TrainStep(model, 256, lr=1e-3)
+step = TrainStep(model, 256, lr=1e-3, use_graph=graph)
 batch = synthetic_batch(256, (192, 192), 21, 19, dev, 1234)
-for _ in range(5): step(*batch)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(40): step(*batch)
-torch.cuda.synchronize(); print(sys.argv[1:] or "default", f"{(time.perf_counter()-t0)/40*1e3:.3f} ms/step")
+for _ in range(8): step(*batch)
+ts = []
+for _ in range(6):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): step(*batch)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 20 * 1e3)
+print(args or "default", "graph" if graph else "eager", f"median {statistics.median(ts):.3f} min {min(ts):.3f} ms/step", flush=True)

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--igemm_tile", type=int, default=0)
     ap.add_argument("--wgrad_tile", type=int, default=0)
     ap.add_argument("--igemm_dbg", type=int, default=0)
+    ap.add_argument("--wgrad_slots", type=int, default=0)
     ap.add_argument("--win_limit", type=int, default=0, help="window-mode LDS limit in KB (default 53)")
     ap.add_argument("--lib", default="", help="A/B: load this build of the library instead of libmtn_hip.so")
     a = ap.parse_args()
@@ -50,6 +51,7 @@ def main():
     _lib.call("mtn_debug_set", 6, a.igemm_tile)
     _lib.call("mtn_debug_set", 7, a.wgrad_tile)
     _lib.call("mtn_debug_set", 8, a.igemm_dbg)
+    _lib.call("mtn_debug_set", 10, a.wgrad_slots)
     if a.win_limit:
         _lib.call("mtn_debug_set", 9, a.win_limit)
     dev = torch.device("cuda:0")
