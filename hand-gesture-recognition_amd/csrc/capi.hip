@@ -138,6 +138,26 @@ int mtn_conv1_wgrad(const float* x_nchw, const void* dy, float* dw, float* parti
     return mtn_conv1_wgrad_run(x_nchw, dy, dw, partial, dtype, B, H, W, (hipStream_t)stream);
 }
 
+int mtn_conv1_stats(const float* x_nchw, const void* w, float* stats, int dtype, int B, int H, int W, void* stream) {
+    return mtn_conv1_stats_run(x_nchw, w, stats, dtype, B, H, W, (hipStream_t)stream);
+}
+int mtn_conv1_bn_act(const float* x_nchw, const void* w, const float* scale_shift, void* out, int act, int dtype, int B,
+                     int H, int W, void* stream) {
+    return mtn_conv1_bn_act_run(x_nchw, w, scale_shift, out, act, dtype, B, H, W, (hipStream_t)stream);
+}
+int mtn_conv1_bwd_partial_rows(int B, int H, int W) {
+    const int blocks = mtn_conv1_bwd_blocks((long)B * (H / 2) * (W / 2));
+    // producer rows (+ the column-sum scratch the library appends) + one row for the sums themselves
+    return mtn_reduce_rows_needed(blocks) + 1;
+}
+int mtn_conv1_bwd_partial_width(void) { return mtn_conv1_bwd_width(); }
+int mtn_conv1_bwd(const float* x_nchw, const void* w, const void* dout, const float* scale_shift, const float* mean_rstd,
+                  float* partial, float* dgamma, float* dbeta, float* dw, int act, int dtype, int B, int H, int W,
+                  void* stream) {
+    return mtn_conv1_bwd_run(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, dw, act, dtype, B, H, W,
+                             (hipStream_t)stream);
+}
+
 int mtn_slab_rows(int rows) { return mtn_reduce_rows_needed(rows); }
 
 int mtn_bn_finalize(float* stats, int tiles, int C, long long count, const float* gamma, const float* beta,

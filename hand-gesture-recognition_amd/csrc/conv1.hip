@@ -3,6 +3,22 @@
 // from the dataloader's NCHW fp32 image (no layout pass over the input; libs/load.py:46-50 batch
 // contract), pad K to 32 and run one-K-step MFMA GEMMs; the forward writes the NHWC activation the
 // rest of the backbone uses.  No data gradient: the image needs none.
+//
+// Fused stem (what the training plan runs): the layer is so cheap to recompute (K = 27) and its
+// output so large (B x 96 x 96 x 64: 302 MB in bf16 at B = 256, the largest tensor of the network)
+// that the RAW conv output is never stored:
+//   conv1_fused<STATS>   pass 1: conv -> BN partial statistics only          (reads the image)
+//   conv1_fused<BNACT>   pass 2: conv -> scale/shift -> SiLU -> NHWC activation (reads the image again)
+//   conv1_bwd            ONE backward pass over (image, d activation): recomputes the conv, forms
+//                        dz = g * silu'(z) and contracts over the pixel axis
+//                            P[n][k] = sum_px [dz | a][px][n] * a[px][k]      a = 27-tap patch, a[27] = 1
+//                        which holds sum dz*x (the weight-gradient core), sum dz (dbeta), the patch Gram
+//                        matrix G = sum a a^T and sum a; with S2 = sum dz*xhat (dgamma) the BatchNorm
+//                        backward folds into a closed form (conv1_bwd_finalize):
+//                            d raw = scale (dz - m1 - xhat m2),  xhat = rstd (W a - mean)
+//                            dW[c][k] = scale_c ( P[c][k] - m1_c Sa[k] - m2_c rstd_c ( (W G)[c][k] - mean_c Sa[k] ) )
+//                        -- no d raw tensor, no separate BN reduce / apply passes (they were 3 + 2 sweeps
+//                        over 302 MB tensors), and the weight gradient sees un-rounded d raw.
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
@@ -17,10 +33,12 @@ constexpr int CO = 64, KK = 27, PXB = 256;    // output channels, taps*cin, pixe
 // matrix is 64 x 32 in LDS.  The C tile is staged through LDS in T so the 32 KB of NHWC output
 // of a workgroup is one fully coalesced block of 16-byte stores and the BN partial statistics
 // are column sums of exactly the stored values.
-template <class T>
+// MODE 0: raw output + statistics of the stored values (mtn_conv1_fwd); 1: statistics only, from the
+// fp32 accumulators (nothing is stored); 2: y = act(conv * scale + shift), no statistics.
+template <class T, int MODE = 0>
 __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
                                                         T* __restrict__ y, float* __restrict__ stats, int B, int H,
-                                                        int W, int OH, int OW) {
+                                                        int W, int OH, int OW, const float* __restrict__ ss, int act) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KP = 32;                                   // padded K
     constexpr int PA = KP + 16 / (int)sizeof(T);             // LDS pitch of A / W rows (elements)
@@ -76,6 +94,37 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
         }
     }
     __syncthreads();
+    if (MODE == 1) {
+        // column sums straight from the accumulators: lane holds pixels 4*(lane>>4)+r of fragment i,
+        // channel j*16 + (lane&15); rows past M are all-zero patches and add nothing
+        float* red = reinterpret_cast<float*>(smem);         // [2][4][64]
+        MTN_UNROLL for (int j = 0; j < 4; ++j) {
+            float sv = 0.f, sq = 0.f;
+            MTN_UNROLL for (int i = 0; i < 4; ++i)
+                MTN_UNROLL for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; sv += v; sq += v * v; }
+            sv += __shfl_xor(sv, 16, 64); sq += __shfl_xor(sq, 16, 64);
+            sv += __shfl_xor(sv, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            if (lane < 16) { red[wid * 64 + j * 16 + lane] = sv; red[256 + wid * 64 + j * 16 + lane] = sq; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            const float* q = red + which * 256 + c;
+            stats[((long)blockIdx.x * 2 + which) * CO + c] = q[0] + q[64] + q[128] + q[192];
+        }
+        return;
+    }
+    if (MODE == 2) {
+        MTN_UNROLL for (int j = 0; j < 4; ++j) {
+            const int c = j * 16 + (lane & 15);
+            const float sc = ss[c], sh = ss[CO + c];
+            MTN_UNROLL for (int i = 0; i < 4; ++i)
+                MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                    const float z = acc[i][j][r] * sc + sh;
+                    acc[i][j][r] = act == MTN_ACT_SILU ? siluf_(z) : z;
+                }
+        }
+    }
     MTN_UNROLL for (int i = 0; i < 4; ++i)
         MTN_UNROLL for (int j = 0; j < 4; ++j)
             MTN_UNROLL for (int r = 0; r < 4; ++r)
@@ -87,7 +136,7 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
         const long mm = (long)blockIdx.x * PXB + row;
         if (mm < M) *reinterpret_cast<chunk16*>(y + mm * CO + col) = *reinterpret_cast<const chunk16*>(sC + row * PC + col);
     }
-    if (stats) {
+    if (MODE == 0 && stats) {
         const int c = tid & 63, part = tid >> 6;
         float s = 0.f, ss = 0.f;
         long rows = M - (long)blockIdx.x * PXB;
@@ -169,6 +218,150 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     }
 }
 
+// ---- fused backward of the stem (see the header) ---------------------------------------------------
+constexpr int BW_N = CO + 32;                 // contraction columns [dz (64) | patch (32)]
+constexpr int BW_W = BW_N * 32 + CO;          // floats per partial row: P[96][32] then S2[64]
+constexpr int ONE_K = KK;                     // patch slot that carries the constant 1
+
+// Work split per 64-pixel step (256 threads): the loaders stage the d-activation tile and the im2col
+// patches through registers one step AHEAD (the global latency sits under the previous step's math);
+// wave w recomputes raw[ch 16w..16w+15][64 px] (weight fragment as the MFMA row operand, loaded once:
+// a lane's quad is 4 consecutive channels of one pixel, so it needs only 4 x 4 BatchNorm constants),
+// forms dz, keeps sum dz*xhat in 4 registers and writes dz to LDS for the pixel contraction.
+template <class T, bool TR>
+__global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
+                                                        const T* __restrict__ dout, const float* __restrict__ ss,
+                                                        const float* __restrict__ mr, float* __restrict__ partial, int B,
+                                                        int H, int W, int OH, int OW, int px_per_block, int act) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
+    constexpr int PY = CO + 16 / (int)sizeof(T), PA = 32 + 16 / (int)sizeof(T);
+    constexpr int GCH = WPX * (CO / VEC) / 256;                  // d-activation chunks per thread per step (2 / 4)
+    __shared__ __attribute__((aligned(16))) T sA[WPX * PA];      // patches [px][32]
+    __shared__ __attribute__((aligned(16))) T sB[CO * PA];       // weights [co][32]
+    __shared__ __attribute__((aligned(16))) T sG[WPX * PY];      // d activation [px][64]
+    __shared__ __attribute__((aligned(16))) T sD[WPX * PY];      // dz [px][64]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    {
+        const int n = tid >> 2, k0 = (tid & 3) * 8;
+        float v[8];
+        MTN_UNROLL for (int e = 0; e < 8; ++e) v[e] = (k0 + e < KK) ? to_f<T>(w[n * KK + k0 + e]) : 0.f;
+        MTN_UNROLL for (int c = 0; c < 8; c += VEC) *reinterpret_cast<chunk16*>(sB + n * PA + k0 + c) = pack<T>(v + c);
+    }
+    const unsigned M = (unsigned)((long)B * OH * OW);             // < 2^31 (host-checked)
+    const unsigned m0 = blockIdx.x * (unsigned)px_per_block;
+    unsigned m1 = m0 + (unsigned)px_per_block;
+    if (m1 > M) m1 = M;
+    const unsigned ohw = (unsigned)(OH * OW);
+    // this lane's 4 channels and their constants: z = raw*sc + sh, xhat = raw*rs + b2
+    const int c0 = wid * 16 + 4 * (lane >> 4);
+    float k_sc[4], k_sh[4], k_rs[4], k_b2[4], s2[4];
+    MTN_UNROLL for (int r = 0; r < 4; ++r) {
+        const float mean = mr[c0 + r], rstd = mr[CO + c0 + r];
+        k_sc[r] = ss[c0 + r]; k_sh[r] = ss[CO + c0 + r]; k_rs[r] = rstd; k_b2[r] = -mean * rstd; s2[r] = 0.f;
+    }
+    // loader state: d-activation chunks (row, column) and the patch slice (pixel tid/4, k = 8*(tid%4) .. +7)
+    chunk16 rg[GCH];
+    float rv[8];
+    const int pr = tid >> 2, pk0 = (tid & 3) * 8;
+    auto fetch = [&](unsigned mb) {
+        MTN_UNROLL for (int i = 0; i < GCH; ++i) {
+            const int q = tid + i * 256, r = q / (CO / VEC), c = (q - r * (CO / VEC)) * VEC;
+            rg[i] = (mb + r < m1) ? *reinterpret_cast<const chunk16*>(dout + (long)(mb + r) * CO + c) : zero_chunk();
+        }
+        MTN_UNROLL for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+        const unsigned m = mb + pr;
+        if (m < m1) {
+            const unsigned b = m / ohw, rem = m - b * ohw;
+            const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+            MTN_UNROLL for (int e = 0; e < 8; ++e) {
+                const int kk = pk0 + e;
+                const int iy = 2 * oy - 1 + kk / 9, ix = 2 * ox - 1 + (kk / 3) % 3;
+                if (kk < KK && iy >= 0 && iy < H && ix >= 0 && ix < W) rv[e] = x[(((long)b * 3 + kk % 3) * H + iy) * W + ix];
+                if (kk == ONE_K) rv[e] = 1.f;                     // slot 27 carries the constant 1
+            }
+        }
+    };
+    auto stage = [&]() {
+        MTN_UNROLL for (int i = 0; i < GCH; ++i) {
+            const int q = tid + i * 256, r = q / (CO / VEC), c = (q - r * (CO / VEC)) * VEC;
+            *reinterpret_cast<chunk16*>(sG + r * PY + c) = rg[i];
+        }
+        MTN_UNROLL for (int c = 0; c < 8; c += VEC) *reinterpret_cast<chunk16*>(sA + pr * PA + pk0 + c) = pack<T>(rv + c);
+    };
+    f32x4_t out3[3];
+    out3[0] = out3[1] = out3[2] = zero4();
+    __syncthreads();                                              // sB
+    // the weight fragment of this wave's 16 channels: the row operand of every raw MFMA
+    typename Mma<T>::Frag fw[32 / KI];
+    MTN_UNROLL for (int ks = 0; ks < 32 / KI; ++ks)
+        fw[ks] = Mma<T>::load(sB + (wid * 16 + (lane & 15)) * PA + ks * KI + (lane >> 4) * (KI / 4));
+    if (m0 < m1) fetch(m0);
+    for (unsigned mb = m0; mb < m1; mb += WPX) {
+        stage();
+        __syncthreads();
+        if (mb + WPX < m1) fetch(mb + WPX);                       // in flight during this step's math
+        MTN_UNROLL for (int i = 0; i < 4; ++i) {                  // pixel fragment i: pixel p = 16 i + (lane & 15)
+            const int p = i * 16 + (lane & 15);
+            f32x4_t raw = zero4();
+            MTN_UNROLL for (int ks = 0; ks < 32 / KI; ++ks)
+                raw = Mma<T>::mma(fw[ks], Mma<T>::load(sA + p * PA + ks * KI + (lane >> 4) * (KI / 4)), raw);
+            float g[4];
+            MTN_UNROLL for (int r = 0; r < 4; ++r) g[r] = to_f<T>(sG[p * PY + c0 + r]);
+            f32x4_t dz;
+            MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                const float z = raw[r] * k_sc[r] + k_sh[r];
+                const float d = act == MTN_ACT_SILU ? g[r] * silu_grad_(z) : g[r];
+                s2[r] += d * (raw[r] * k_rs[r] + k_b2[r]);
+                dz[r] = d;
+            }
+            store4<T>(sD + p * PY + c0, dz);
+        }
+        __syncthreads();
+        // contraction over the 64 pixels of the step: out[n][k], fragments id = 3*wid + q -> (n = id/2, k = id%2)
+        MTN_UNROLL for (int ks = 0; ks < WPX / KI; ++ks) {
+            MTN_UNROLL for (int q = 0; q < 3; ++q) {
+                const int id = 3 * wid + q, nf = id >> 1, kf = id & 1;
+                const typename Mma<T>::Frag fa = nf < 4 ? ColFrag<T, TR>::load(sD + ks * KI * PY + nf * 16, PY, lane)
+                                                        : ColFrag<T, TR>::load(sA + ks * KI * PA + (nf - 4) * 16, PA, lane);
+                out3[q] = Mma<T>::mma(fa, ColFrag<T, TR>::load(sA + ks * KI * PA + kf * 16, PA, lane), out3[q]);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + (long)blockIdx.x * BW_W;
+    MTN_UNROLL for (int q = 0; q < 3; ++q) {
+        const int id = 3 * wid + q, nf = id >> 1, kf = id & 1;
+        MTN_UNROLL for (int r = 0; r < 4; ++r)
+            out[(nf * 16 + 4 * (lane >> 4) + r) * 32 + kf * 16 + (lane & 15)] = out3[q][r];
+    }
+    MTN_UNROLL for (int r = 0; r < 4; ++r) {                      // sum dz*xhat: over the 16 pixel lanes of the wave
+        float v = s2[r];
+        MTN_UNROLL for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((lane & 15) == 0) out[BW_N * 32 + c0 + r] = v;        // one writer per channel
+    }
+}
+
+// sums[BW_W] (column sums of the partial slab) -> dgamma, dbeta, dW (OIHW); one block
+template <class T>
+__global__ __launch_bounds__(256) void conv1_bwd_finalize_kernel(const float* __restrict__ sums, const T* __restrict__ w,
+                                                                 const float* __restrict__ ss, const float* __restrict__ mr,
+                                                                 double count, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dw) {
+    for (int t = threadIdx.x; t < CO * KK; t += 256) {
+        const int c = t / KK, k = t - c * KK;
+        const double S1 = sums[c * 32 + ONE_K], S2 = sums[BW_N * 32 + c];
+        const double Sa = sums[(CO + ONE_K) * 32 + k];                       // sum of patch element k
+        double WG = 0.0;                                                      // sum_px raw[c] * a[k] = (W G)[c][k]
+        for (int q = 0; q < KK; ++q) WG += (double)to_f<T>(w[c * KK + q]) * (double)sums[(CO + q) * 32 + k];
+        const double mean = mr[c], rstd = mr[CO + c];
+        const double m1 = S1 / count, m2 = S2 / count;
+        const double v = (double)ss[c] * ((double)sums[c * 32 + k] - m1 * Sa - m2 * rstd * (WG - mean * Sa));
+        dw[c * KK + (k % 3) * 9 + (k / 9) * 3 + (k / 3) % 3] = (float)v;
+        if (k == 0) { dbeta[c] = (float)S1; dgamma[c] = (float)S2; }
+    }
+}
+
 }  // namespace
 
 int mtn_conv1_tiles(long M) { return (int)((M + PXB - 1) / PXB); }
@@ -182,16 +375,16 @@ int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int 
     const int blocks = mtn_conv1_tiles(M);
     if (dtype == MTN_BF16) {
         const size_t lds = (size_t)PXB * (CO + 8) * 2;       // C tile (bf16) >= A + W tiles
-        MTN_LAUNCH(conv1_fwd_kernel<bf16_t>, dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
-                   H, W, OH, OW);
+        MTN_LAUNCH((conv1_fwd_kernel<bf16_t, 0>), dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
+                   H, W, OH, OW, (const float*)nullptr, 0);
     } else {
         const size_t lds = (size_t)PXB * (CO + 4) * 4;
 #ifndef MTN_EMU
         static MtnLdsAttr attr;
-        mtn_set_max_lds(attr, &conv1_fwd_kernel<float>, lds);
+        mtn_set_max_lds(attr, &conv1_fwd_kernel<float, 0>, lds);
 #endif
-        MTN_LAUNCH(conv1_fwd_kernel<float>, dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
-                   W, OH, OW);
+        MTN_LAUNCH((conv1_fwd_kernel<float, 0>), dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
+                   W, OH, OW, (const float*)nullptr, 0);
     }
     return mtn_check_launch("conv1_fwd");
 }
@@ -214,4 +407,76 @@ int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partia
     int rc = mtn_check_launch("conv1_wgrad");
     if (rc) return rc;
     return mtn_colsum_run(partial, blocks, CO * KK, dw, stream);
+}
+
+// ---- fused stem -------------------------------------------------------------------------------------
+template <int MODE>
+static int conv1_fused_launch(const float* x, const void* w, void* y, float* stats, const float* ss, int act, int dtype,
+                              int B, int H, int W, hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv1: bad geometry %dx%dx%d", B, H, W);
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "conv1: bad dtype %d", dtype);
+    const int OH = H / 2, OW = W / 2;
+    const long M = (long)B * OH * OW;
+    MTN_REQUIRE(M * CO < (1L << 31), "conv1: tensor too large");
+    const int blocks = mtn_conv1_tiles(M);
+    if (dtype == MTN_BF16) {
+        const size_t lds = (size_t)PXB * (CO + 8) * 2;
+        MTN_LAUNCH((conv1_fwd_kernel<bf16_t, MODE>), dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
+                   H, W, OH, OW, ss, act);
+    } else {
+        const size_t lds = (size_t)PXB * (CO + 4) * 4;
+#ifndef MTN_EMU
+        static MtnLdsAttr attr;
+        mtn_set_max_lds(attr, &conv1_fwd_kernel<float, MODE>, lds);
+#endif
+        MTN_LAUNCH((conv1_fwd_kernel<float, MODE>), dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
+                   W, OH, OW, ss, act);
+    }
+    return mtn_check_launch("conv1_fused");
+}
+
+int mtn_conv1_stats_run(const float* x, const void* w, float* stats, int dtype, int B, int H, int W, hipStream_t stream) {
+    MTN_REQUIRE(x && w && stats, "conv1_stats: null operand");
+    return conv1_fused_launch<1>(x, w, nullptr, stats, nullptr, 0, dtype, B, H, W, stream);
+}
+
+int mtn_conv1_bn_act_run(const float* x, const void* w, const float* scale_shift, void* out, int act, int dtype, int B, int H,
+                         int W, hipStream_t stream) {
+    MTN_REQUIRE(x && w && scale_shift && out, "conv1_bn_act: null operand");
+    MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "conv1_bn_act: act=%d", act);
+    return conv1_fused_launch<2>(x, w, out, nullptr, scale_shift, act, dtype, B, H, W, stream);
+}
+
+static const int kBwdPx = 2048;
+int mtn_conv1_bwd_blocks(long M) { return (int)((M + kBwdPx - 1) / kBwdPx); }
+int mtn_conv1_bwd_width(void) { return BW_W; }
+
+// partial: f32 [mtn_reduce_rows_needed(mtn_conv1_bwd_blocks(M)) + 1][BW_W] (the last row receives the column sums)
+int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const float* scale_shift, const float* mean_rstd,
+                      float* partial, float* dgamma, float* dbeta, float* dw, int act, int dtype, int B, int H, int W,
+                      hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv1_bwd: bad geometry");
+    MTN_REQUIRE(x && w && dout && scale_shift && mean_rstd && partial && dgamma && dbeta && dw, "conv1_bwd: null operand");
+    MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "conv1_bwd: act=%d", act);
+    const int OH = H / 2, OW = W / 2;
+    const long M = (long)B * OH * OW;
+    const int blocks = mtn_conv1_bwd_blocks(M);
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH((conv1_bwd_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, x, (const bf16_t*)w, (const bf16_t*)dout,
+                   scale_shift, mean_rstd, partial, B, H, W, OH, OW, kBwdPx, act);
+    else
+        MTN_LAUNCH((conv1_bwd_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, x, (const float*)w, (const float*)dout,
+                   scale_shift, mean_rstd, partial, B, H, W, OH, OW, kBwdPx, act);
+    int rc = mtn_check_launch("conv1_bwd");
+    if (rc) return rc;
+    float* sums = partial + (long)mtn_reduce_rows_needed(blocks) * BW_W;     // after the slab and its folding scratch
+    rc = mtn_colsum_run(partial, blocks, BW_W, sums, stream);
+    if (rc) return rc;
+    if (dtype == MTN_BF16)
+        MTN_LAUNCH(conv1_bwd_finalize_kernel<bf16_t>, dim3(1), dim3(256), 0, stream, (const float*)sums, (const bf16_t*)w, scale_shift,
+                   mean_rstd, (double)M, dgamma, dbeta, dw);
+    else
+        MTN_LAUNCH(conv1_bwd_finalize_kernel<float>, dim3(1), dim3(256), 0, stream, (const float*)sums, (const float*)w, scale_shift,
+                   mean_rstd, (double)M, dgamma, dbeta, dw);
+    return mtn_check_launch("conv1_bwd_finalize");
 }

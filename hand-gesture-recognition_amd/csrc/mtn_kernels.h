@@ -77,6 +77,14 @@ int mtn_conv1_tiles(long M);
 int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int dtype, int B, int H, int W,
                       hipStream_t stream);
 int mtn_conv1_wgrad_blocks(long M);
+int mtn_conv1_stats_run(const float* x, const void* w, float* stats, int dtype, int B, int H, int W, hipStream_t stream);
+int mtn_conv1_bn_act_run(const float* x, const void* w, const float* scale_shift, void* out, int act, int dtype, int B, int H,
+                         int W, hipStream_t stream);
+int mtn_conv1_bwd_blocks(long M);
+int mtn_conv1_bwd_width(void);
+int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const float* scale_shift, const float* mean_rstd,
+                      float* partial, float* dgamma, float* dbeta, float* dw, int act, int dtype, int B, int H, int W,
+                      hipStream_t stream);
 int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partial, int dtype, int B, int H, int W,
                         hipStream_t stream);
 

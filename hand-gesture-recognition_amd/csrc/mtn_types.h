@@ -229,7 +229,17 @@ __device__ __forceinline__ void buf_glds16(const BufDesc& d, unsigned voff, void
 }
 
 // ---- small math -----------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1/x by v_rcp_f32 (1 ulp).  A plain `1.0f / x` compiles to the correctly rounded division sequence
+// (v_div_scale x2, v_rcp, 4-5 v_fma, v_div_fmas, v_div_fixup: ~12 instructions), which made the
+// BatchNorm / SiLU elementwise kernels VALU-bound below the HBM rate.
+__device__ __forceinline__ float rcpf_(float x) {
+#ifdef MTN_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_grad_(float x) {   // d/dx x*sigmoid(x)
     const float s = sigmoidf_(x);

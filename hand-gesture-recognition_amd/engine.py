@@ -138,17 +138,20 @@ class Engine:
         for u in units:
             M = B * u.hout * u.wout
             u.M = M
-            u.raw = self._new((B, u.hout, u.wout, u.cout))
+            # the stem is fused (conv1.hip): its raw output -- the largest tensor of the network -- is
+            # recomputed from the image instead of stored
+            u.raw = self._new((B, u.hout, u.wout, u.cout)) if u is not self.u_conv1 else None
             if u.bn:
                 tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_stats_tiles(M, u.cout, u.k * u.k * u.cin)
                 u.tiles = tiles
                 u.stats = self._f32(ops.slab_rows(tiles), 2, u.cout)
                 u.ss, u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout), self._f32(2, u.cout)
-                max_part = max(max_part, ops.bn_bwd_partial_rows(M) * 2 * u.cout)
-            max_dy = max(max_dy, M * u.cout)
+                if u is not self.u_conv1:
+                    max_part = max(max_part, ops.bn_bwd_partial_rows(M) * 2 * u.cout)
             if u is self.u_conv1:
-                self.conv1_part = self._f32(ops.conv1_wgrad_partial_rows(B, self.H, self.W), 64 * 27)
+                self.conv1_part = self._f32(*ops.conv1_bwd_partial_shape(B, self.H, self.W))
             else:
+                max_dy = max(max_dy, M * u.cout)
                 max_ws = max(max_ws, ops.conv_wgrad_workspace_bytes(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s))
         Mt = B * self.N
         for n_out, k_in in ((768, 256), (256, 256)):
@@ -241,10 +244,15 @@ class Engine:
     # ---------------------------------------------------------------- forward
     def backbone_forward(self, x, training=True):
         """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512]."""
-        u1 = self.u_conv1
+        u1, bn1 = self.u_conv1, self.u_conv1.mod.bn
         self.x_in = x
-        ops.conv1_fwd(x, u1.wf, u1.raw, u1.stats if training else None)
-        self._bn_fwd(u1, self.a1, training)
+        if training:
+            ops.conv1_stats(x, u1.wf, u1.stats)
+            ops.bn_finalize(u1.stats, u1.tiles, u1.M, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                            bn1.num_batches_tracked, u1.ss, u1.mr, bn1.momentum, bn1.eps)
+        else:
+            ops.bn_eval_scale_shift(bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, u1.ss, bn1.eps)
+        ops.conv1_bn_act(x, u1.wf, u1.ss, self.a1, _ACT[u1.act])
         self._conv(self.u_conv2, self.a1, self.a2, training)
         cur = self.a2
         for st in self.stages:
@@ -344,10 +352,8 @@ class Engine:
             self._ready(("stage", self.stages.index(st)))
         self._conv_bwd(self.u_conv2, self.g_a2, self.a1, self.g_a1)
         u1, bn = self.u_conv1, self.u_conv1.mod.bn
-        dy = self._dy(u1)
-        ops.bn_act_bwd(self.g_a1, u1.raw, None, u1.ss, u1.mr, self.bn_part, u1.coef, self._g(bn.weight),
-                       self._g(bn.bias), dy, ops.ACT_SILU)
-        ops.conv1_wgrad(self.x_in, dy, self._g(u1.weight), self.conv1_part)
+        ops.conv1_bwd(self.x_in, u1.wf, self.g_a1, u1.ss, u1.mr, self.conv1_part, self._g(bn.weight), self._g(bn.bias),
+                      self._g(u1.weight), _ACT[u1.act])
         self._ready("stem")
 
     def backward(self, dlogits=None, dhm=None):

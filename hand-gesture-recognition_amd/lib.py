@@ -28,6 +28,11 @@ _PROTOS = {
     "mtn_conv1_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mtn_conv1_wgrad_partial_rows": [_i, _i, _i],
     "mtn_conv1_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mtn_conv1_stats": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mtn_conv1_bn_act": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_conv1_bwd_partial_rows": [_i, _i, _i],
+    "mtn_conv1_bwd_partial_width": [],
+    "mtn_conv1_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_slab_rows": [_i],
     "mtn_bn_finalize": [_vp, _i, _i, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp],
     "mtn_bn_eval_scale_shift": [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
@@ -65,6 +70,7 @@ _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_
 _STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
                 "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
+                "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",
                 "mtn_loss_partial_len"}   # return a value, not a status
 
 _lib = None

@@ -182,6 +182,39 @@ def conv1_wgrad(x_nchw, dy, dw, partial):
              dtype_code(dy), B, H, W, _stream(dy))
 
 
+def conv1_stats(x_nchw, w, stats):
+    """fused stem, pass 1: BN partial statistics of conv(x) (nothing else is stored)."""
+    B, _, H, W = x_nchw.shape
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and stats.dtype == torch.float32
+    assert stats.numel() >= conv1_stats_tiles(B, H, W) * 128
+    lib.call("mtn_conv1_stats", x_nchw.data_ptr(), w.data_ptr(), stats.data_ptr(), dtype_code(w), B, H, W, _stream(stats))
+
+
+def conv1_bn_act(x_nchw, w, scale_shift, out, act):
+    """fused stem, pass 2: out [B,H/2,W/2,64] = act(conv(x) * scale + shift)."""
+    B, _, H, W = x_nchw.shape
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and out.is_contiguous()
+    assert tuple(out.shape) == (B, H // 2, W // 2, 64) and out.dtype == w.dtype
+    lib.call("mtn_conv1_bn_act", x_nchw.data_ptr(), w.data_ptr(), scale_shift.data_ptr(), out.data_ptr(), act,
+             dtype_code(out), B, H, W, _stream(out))
+
+
+def conv1_bwd_partial_shape(B, H, W):
+    return lib.call("mtn_conv1_bwd_partial_rows", B, H, W), lib.call("mtn_conv1_bwd_partial_width")
+
+
+def conv1_bwd(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, dw, act):
+    """fused stem backward: dgamma, dbeta [64] and dw f32 [64,3,3,3] from (x, d activation) in one pass."""
+    B, _, H, W = x_nchw.shape
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and dout.is_contiguous() and dw.is_contiguous()
+    assert tuple(dout.shape) == (B, H // 2, W // 2, 64) and dout.dtype == w.dtype
+    rows, width = conv1_bwd_partial_shape(B, H, W)
+    assert partial.dtype == torch.float32 and partial.numel() >= rows * width
+    lib.call("mtn_conv1_bwd", x_nchw.data_ptr(), w.data_ptr(), dout.data_ptr(), scale_shift.data_ptr(),
+             mean_rstd.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dw.data_ptr(), act,
+             dtype_code(dout), B, H, W, _stream(dout))
+
+
 # ---- ViT encoder --------------------------------------------------------------------------------
 def tokens_fwd(feat, pos, cls, tok):
     """feat [B*P,256] (+pos f32 [P,256]) and cls f32 [256] -> tok [B,P+1,256]."""

@@ -67,6 +67,24 @@ int mtn_conv1_wgrad_partial_rows(int B, int H, int W);
 int mtn_conv1_wgrad(const float* x_nchw, const void* dy, float* dw, float* partial, int dtype, int B,
                     int H, int W, void* stream);
 
+/* Fused stem for training: the RAW conv output (the largest tensor of the network) is never stored.
+ *   mtn_conv1_stats   conv -> stats[mtn_conv1_stats_tiles][2][64] only (BN partial sums of the fp32 results)
+ *   mtn_conv1_bn_act  conv -> out = act(conv * scale + shift), NHWC [B][H/2][W/2][64]  (scale_shift[2][64]
+ *                     from mtn_bn_finalize, or mtn_bn_eval_scale_shift in eval mode)
+ *   mtn_conv1_bwd     backward of act(bn(conv(x))) in ONE pass over (x, dout): recomputes the conv,
+ *                     dgamma / dbeta [64] and dw f32 [64][3][3][3] OIHW (all overwritten) -- replaces
+ *                     BN-backward reduce + apply + mtn_conv1_wgrad.  partial: f32
+ *                     [mtn_conv1_bwd_partial_rows][mtn_conv1_bwd_partial_width] workspace. */
+int mtn_conv1_stats(const float* x_nchw, const void* w, float* stats, int dtype, int B, int H, int W,
+                    void* stream);
+int mtn_conv1_bn_act(const float* x_nchw, const void* w, const float* scale_shift, void* out, int act,
+                     int dtype, int B, int H, int W, void* stream);
+int mtn_conv1_bwd_partial_rows(int B, int H, int W);
+int mtn_conv1_bwd_partial_width(void);
+int mtn_conv1_bwd(const float* x_nchw, const void* w, const void* dout, const float* scale_shift,
+                  const float* mean_rstd, float* partial, float* dgamma, float* dbeta, float* dw,
+                  int act, int dtype, int B, int H, int W, void* stream);
+
 /* ---- nn.Linear / 1x1 projections  (model/transformer.py:34-37,56-58; multitasknet.py:13) ------
  * out = act(x @ w^T + bias) + res ; w is [N][K]; aux_out (optional) gets the pre-activation. */
 int mtn_linear_fwd(const void* x, int ldx, const void* w, const float* bias, int act,

@@ -256,3 +256,44 @@ def test_conv1_fwd_wgrad(be, dtype, cfg):
     ops.conv1_wgrad(xd, dy.to(d), dw, part)
     be.sync()
     assert rel_err(dw, wq.grad) < tol(dtype, 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 16, 16), (1, 12, 20), (3, 8, 8)])
+def test_conv1_fused_stem(be, dtype, cfg):
+    """stats-only pass, conv+BN+SiLU pass and the one-pass backward (recomputed conv, closed-form BN
+    backward, weight gradient from the pixel contraction) against torch autograd of SiLU(BN(conv(x)))."""
+    B, H, W = cfg
+    d = be.device
+    x = _rand((B, 3, H, W), torch.float32, 51)
+    w = (_rand((64, 3, 3, 3), torch.float32, 52) / 27 ** 0.5)
+    gamma, beta = 1 + 0.2 * _rand((64,), torch.float32, 53), 0.1 * _rand((64,), torch.float32, 54)
+    # reference on the operands as the kernels see them (bf16 mode rounds x patches and w)
+    xq, wq = x.to(dtype).float(), w.to(dtype).float()
+    wr, gr, br = wq.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    raw = F.conv2d(xq, wr, None, 2, 1)
+    z = F.batch_norm(raw, None, None, gr, br, True, 0.1, 1e-5)
+    out_ref = F.silu(z)
+    dout = _rand((B, H // 2, W // 2, 64), dtype, 55)
+    out_ref.backward(dout.float().permute(0, 3, 1, 2))
+    M = B * (H // 2) * (W // 2)
+    xd, wd = x.to(d), pack_krsc(w, dtype).to(d)
+    tiles = ops.conv1_stats_tiles(B, H, W)
+    stats = torch.full((ops.slab_rows(tiles), 2, 64), float("nan"), device=d)
+    ops.conv1_stats(xd, wd, stats)
+    ss, mr = torch.empty(2, 64, device=d), torch.empty(2, 64, device=d)
+    ops.bn_finalize(stats, tiles, M, gamma.to(d), beta.to(d), None, None, None, ss, mr)
+    out = torch.full((B, H // 2, W // 2, 64), float("nan"), dtype=dtype, device=d)
+    ops.conv1_bn_act(xd, wd, ss, out, ops.ACT_SILU)
+    be.sync()
+    rawf = raw.detach().permute(0, 2, 3, 1).reshape(M, 64)
+    assert rel_err(stats[:tiles].sum(0)[0], rawf.sum(0)) < 1e-3 or float((stats[:tiles].cpu().sum(0)[0] - rawf.sum(0)).abs().max()) < 1e-3
+    assert rel_err(mr[0], rawf.mean(0)) < 1e-4 or float((mr[0].cpu() - rawf.mean(0)).abs().max()) < 1e-5
+    assert rel_err(out.float(), out_ref.permute(0, 2, 3, 1)) < tol(dtype, 1e-4, 2e-2)
+    rows, width = ops.conv1_bwd_partial_shape(B, H, W)
+    part = torch.full((rows, width), float("nan"), device=d)
+    dg, db, dw = torch.empty(64, device=d), torch.empty(64, device=d), torch.empty(64, 3, 3, 3, device=d)
+    ops.conv1_bwd(xd, wd, dout.to(d), ss, mr, part, dg, db, dw, ops.ACT_SILU)
+    be.sync()
+    assert rel_err(dg, gr.grad) < tol(dtype, 2e-4, 2e-2) and rel_err(db, br.grad) < tol(dtype, 2e-4, 2e-2)
+    assert rel_err(dw, wr.grad) < tol(dtype, 5e-4, 3e-2)
