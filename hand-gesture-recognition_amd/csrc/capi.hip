@@ -292,6 +292,8 @@ int mtn_debug_set(int key, int value) {
     if (key == 8) { mtn_igemm_set_dbg(value); return MTN_OK; }
     if (key == 9) { mtn_igemm_set_window_limit(value); return MTN_OK; }
     if (key == 10) { mtn_wgrad_set_slots(value); return MTN_OK; }
+    if (key == 11) { mtn_conv1_set_grid_cap(value); return MTN_OK; }
+    if (key == 12) { mtn_conv1_set_bwd_px(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

@@ -33,12 +33,10 @@ constexpr int CO = 64, KK = 27, PXB = 256;    // output channels, taps*cin, pixe
 // matrix is 64 x 32 in LDS.  The C tile is staged through LDS in T so the 32 KB of NHWC output
 // of a workgroup is one fully coalesced block of 16-byte stores and the BN partial statistics
 // are column sums of exactly the stored values.
-// MODE 0: raw output + statistics of the stored values (mtn_conv1_fwd); 1: statistics only, from the
-// fp32 accumulators (nothing is stored); 2: y = act(conv * scale + shift), no statistics.
-template <class T, int MODE = 0>
+template <class T>
 __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
                                                         T* __restrict__ y, float* __restrict__ stats, int B, int H,
-                                                        int W, int OH, int OW, const float* __restrict__ ss, int act) {
+                                                        int W, int OH, int OW) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KP = 32;                                   // padded K
     constexpr int PA = KP + 16 / (int)sizeof(T);             // LDS pitch of A / W rows (elements)
@@ -94,37 +92,6 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    if (MODE == 1) {
-        // column sums straight from the accumulators: lane holds pixels 4*(lane>>4)+r of fragment i,
-        // channel j*16 + (lane&15); rows past M are all-zero patches and add nothing
-        float* red = reinterpret_cast<float*>(smem);         // [2][4][64]
-        MTN_UNROLL for (int j = 0; j < 4; ++j) {
-            float sv = 0.f, sq = 0.f;
-            MTN_UNROLL for (int i = 0; i < 4; ++i)
-                MTN_UNROLL for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; sv += v; sq += v * v; }
-            sv += __shfl_xor(sv, 16, 64); sq += __shfl_xor(sq, 16, 64);
-            sv += __shfl_xor(sv, 32, 64); sq += __shfl_xor(sq, 32, 64);
-            if (lane < 16) { red[wid * 64 + j * 16 + lane] = sv; red[256 + wid * 64 + j * 16 + lane] = sq; }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int which = tid >> 6, c = tid & 63;
-            const float* q = red + which * 256 + c;
-            stats[((long)blockIdx.x * 2 + which) * CO + c] = q[0] + q[64] + q[128] + q[192];
-        }
-        return;
-    }
-    if (MODE == 2) {
-        MTN_UNROLL for (int j = 0; j < 4; ++j) {
-            const int c = j * 16 + (lane & 15);
-            const float sc = ss[c], sh = ss[CO + c];
-            MTN_UNROLL for (int i = 0; i < 4; ++i)
-                MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                    const float z = acc[i][j][r] * sc + sh;
-                    acc[i][j][r] = act == MTN_ACT_SILU ? siluf_(z) : z;
-                }
-        }
-    }
     MTN_UNROLL for (int i = 0; i < 4; ++i)
         MTN_UNROLL for (int j = 0; j < 4; ++j)
             MTN_UNROLL for (int r = 0; r < 4; ++r)
@@ -136,7 +103,7 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
         const long mm = (long)blockIdx.x * PXB + row;
         if (mm < M) *reinterpret_cast<chunk16*>(y + mm * CO + col) = *reinterpret_cast<const chunk16*>(sC + row * PC + col);
     }
-    if (MODE == 0 && stats) {
+    if (stats) {
         const int c = tid & 63, part = tid >> 6;
         float s = 0.f, ss = 0.f;
         long rows = M - (long)blockIdx.x * PXB;
@@ -152,6 +119,124 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
             const float* q = red + which * 256 + c;
             stats[((long)blockIdx.x * 2 + which) * CO + c] = q[0] + q[64] + q[128] + q[192];
         }
+    }
+}
+
+// Fused-stem forward passes (MODE 1: BN partial statistics from the fp32 accumulators, nothing
+// stored; MODE 2: y = act(conv * scale + shift)).  A workgroup walks tiles of 256 pixels; the 27
+// image taps of a thread's NEXT pixel are fetched into registers before the MFMAs / epilogue of the
+// current tile, so the stride-2 fp32 gather (the cost of these HBM-bound passes) overlaps them.
+template <class T, int MODE>
+__global__ __launch_bounds__(PXB) void conv1_fused_kernel(const float* __restrict__ x, const T* __restrict__ w,
+                                                          T* __restrict__ y, float* __restrict__ stats, int B, int H,
+                                                          int W, int OH, int OW, const float* __restrict__ ss, int act) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KP = 32;
+    constexpr int PA = KP + 16 / (int)sizeof(T);
+    constexpr int PC = CO + 16 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
+    MTN_DYN_SMEM(smem);
+    T* sB = reinterpret_cast<T*>(smem);                      // [64][PA] weights, resident
+    T* sA = sB + CO * PA;                                    // [256][PA] patches of the tile
+    T* sC = sA;                                              // [256][PC] output tile (MODE 2, after the MFMAs)
+    float* red = reinterpret_cast<float*>(sA);               // [2][4][64] (MODE 1, after the MFMAs)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    {
+        const int n = tid >> 2, k0 = (tid & 3) * 8;
+        float v[8];
+        MTN_UNROLL for (int e = 0; e < 8; ++e) v[e] = (k0 + e < KK) ? to_f<T>(w[n * KK + k0 + e]) : 0.f;
+        MTN_UNROLL for (int c = 0; c < 8; c += VEC) *reinterpret_cast<chunk16*>(sB + n * PA + k0 + c) = pack<T>(v + c);
+    }
+    const unsigned M = (unsigned)((long)B * OH * OW), ohw = (unsigned)(OH * OW);
+    const int ntiles = (int)((M + PXB - 1) / PXB);
+    float v[KP];
+    MTN_UNROLL for (int k = KK; k < KP; ++k) v[k] = 0.f;
+    auto gather = [&](int tile) {
+        const unsigned m = (unsigned)tile * PXB + tid;
+        MTN_UNROLL for (int k = 0; k < KK; ++k) v[k] = 0.f;
+        if (m < M) {
+            const unsigned b = m / ohw, rem = m - b * ohw;
+            const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+            const float* xb = x + (long)b * 3 * H * W;
+            // taps are loaded UNDER their validity condition.  (Measured both ways, B = 256: loading every
+            // tap from a clamped address and selecting afterwards -- the usual cure for hipcc's branch
+            // around a conditional load -- was 15 % slower on the two forward passes and 40 % slower on the
+            // backward pass: the clamp / select arithmetic and the extra loads of the 5 padding slots
+            // cost more than the branches, which are wave-uniform almost everywhere.)
+            MTN_UNROLL for (int kh = 0; kh < 3; ++kh) {
+                const int iy = 2 * oy - 1 + kh;
+                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+                MTN_UNROLL for (int kw = 0; kw < 3; ++kw) {
+                    const int ix = 2 * ox - 1 + kw;
+                    const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                    const bool ok = iy == iyc && ix == ixc;
+                    MTN_UNROLL for (int ci = 0; ci < 3; ++ci) {
+                        v[(kh * 3 + kw) * 3 + ci] = 0.f;
+                        if (ok) v[(kh * 3 + kw) * 3 + ci] = xb[(ci * H + iy) * W + ix];
+                    }
+                }
+            }
+        }
+    };
+    float k_sc[4], k_sh[4];
+    if (MODE == 2) {
+        MTN_UNROLL for (int j = 0; j < 4; ++j) { k_sc[j] = ss[j * 16 + (lane & 15)]; k_sh[j] = ss[CO + j * 16 + (lane & 15)]; }
+    }
+    int tile = blockIdx.x;
+    if (tile < ntiles) gather(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        MTN_UNROLL for (int c = 0; c < KP; c += VEC) *reinterpret_cast<chunk16*>(sA + tid * PA + c) = pack<T>(v + c);
+        MTN_BARRIER_LDS();
+        if (tile + (int)gridDim.x < ntiles) gather(tile + gridDim.x);       // in flight under the rest of this tile
+        f32x4_t acc[4][4];
+        MTN_UNROLL for (int i = 0; i < 4; ++i)
+            MTN_UNROLL for (int j = 0; j < 4; ++j) acc[i][j] = zero4();
+        {
+            const T* a = sA + (wid * 64 + (lane & 15)) * PA + (lane >> 4) * (KI / 4);
+            const T* bq = sB + (lane & 15) * PA + (lane >> 4) * (KI / 4);
+            MTN_UNROLL for (int ks = 0; ks < KP / KI; ++ks) {
+                typename Mma<T>::Frag fa[4], fb[4];
+                MTN_UNROLL for (int i = 0; i < 4; ++i) fa[i] = Mma<T>::load(a + i * 16 * PA + ks * KI);
+                MTN_UNROLL for (int j = 0; j < 4; ++j) fb[j] = Mma<T>::load(bq + j * 16 * PA + ks * KI);
+                MTN_UNROLL for (int i = 0; i < 4; ++i)
+                    MTN_UNROLL for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+            }
+        }
+        MTN_BARRIER_LDS();                                     // every wave is done with the patch tile
+        if (MODE == 1) {
+            // column sums straight from the accumulators: lane holds pixels 4*(lane>>4)+r of fragment i,
+            // channel j*16 + (lane&15); rows past M are all-zero patches and add nothing
+            MTN_UNROLL for (int j = 0; j < 4; ++j) {
+                float sv = 0.f, sq = 0.f;
+                MTN_UNROLL for (int i = 0; i < 4; ++i)
+                    MTN_UNROLL for (int r = 0; r < 4; ++r) { const float t = acc[i][j][r]; sv += t; sq += t * t; }
+                sv += __shfl_xor(sv, 16, 64); sq += __shfl_xor(sq, 16, 64);
+                sv += __shfl_xor(sv, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                if (lane < 16) { red[wid * 64 + j * 16 + lane] = sv; red[256 + wid * 64 + j * 16 + lane] = sq; }
+            }
+            MTN_BARRIER_LDS();
+            if (tid < 128) {
+                const int which = tid >> 6, c = tid & 63;
+                const float* q = red + which * 256 + c;
+                stats[((long)tile * 2 + which) * CO + c] = q[0] + q[64] + q[128] + q[192];
+            }
+        } else {
+            MTN_UNROLL for (int i = 0; i < 4; ++i)
+                MTN_UNROLL for (int j = 0; j < 4; ++j)
+                    MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                        const float z = acc[i][j][r] * k_sc[j] + k_sh[j];
+                        sC[(wid * 64 + i * 16 + 4 * (lane >> 4) + r) * PC + j * 16 + (lane & 15)] =
+                            from_f<T>(act == MTN_ACT_SILU ? siluf_(z) : z);
+                    }
+            MTN_BARRIER_LDS();
+            constexpr int CPR = CO / VEC;
+            for (int idx = tid; idx < PXB * CPR; idx += PXB) {
+                const int row = idx / CPR, col = (idx - row * CPR) * VEC;
+                const unsigned mm = (unsigned)tile * PXB + row;
+                if (mm < M) *reinterpret_cast<chunk16*>(y + (long)mm * CO + col) = *reinterpret_cast<const chunk16*>(sC + row * PC + col);
+            }
+        }
+        MTN_BARRIER_LDS();                                     // red / sC are read before the next tile's patches land
     }
 }
 
@@ -228,11 +313,11 @@ constexpr int ONE_K = KK;                     // patch slot that carries the con
 // wave w recomputes raw[ch 16w..16w+15][64 px] (weight fragment as the MFMA row operand, loaded once:
 // a lane's quad is 4 consecutive channels of one pixel, so it needs only 4 x 4 BatchNorm constants),
 // forms dz, keeps sum dz*xhat in 4 registers and writes dz to LDS for the pixel contraction.
-template <class T, bool TR>
+template <class T, bool TR, bool SILU>
 __global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
                                                         const T* __restrict__ dout, const float* __restrict__ ss,
                                                         const float* __restrict__ mr, float* __restrict__ partial, int B,
-                                                        int H, int W, int OH, int OW, int px_per_block, int act) {
+                                                        int H, int W, int OH, int OW, int px_per_block) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KI = Mma<T>::KI;
     constexpr int PY = CO + 16 / (int)sizeof(T), PA = 32 + 16 / (int)sizeof(T);
@@ -264,22 +349,35 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restri
     chunk16 rg[GCH];
     float rv[8];
     const int pr = tid >> 2, pk0 = (tid & 3) * 8;
+    // this thread's 8 taps: row / column offset and channel plane (loop invariant)
+    int t_dy[8], t_dx[8], t_pl[8];
+    MTN_UNROLL for (int e = 0; e < 8; ++e) {
+        const int kk = pk0 + e, kkc = kk < KK ? kk : 0;
+        t_dy[e] = kkc / 9 - 1; t_dx[e] = (kkc / 3) % 3 - 1; t_pl[e] = (kkc % 3) * H * W;
+    }
     auto fetch = [&](unsigned mb) {
-        MTN_UNROLL for (int i = 0; i < GCH; ++i) {
+        MTN_UNROLL for (int i = 0; i < GCH; ++i) {                // rows past the end: loaded from the last row, zeroed by select
             const int q = tid + i * 256, r = q / (CO / VEC), c = (q - r * (CO / VEC)) * VEC;
-            rg[i] = (mb + r < m1) ? *reinterpret_cast<const chunk16*>(dout + (long)(mb + r) * CO + c) : zero_chunk();
+            const unsigned mr_ = mb + r < m1 ? mb + r : m1 - 1;
+            const chunk16 t = *reinterpret_cast<const chunk16*>(dout + (long)mr_ * CO + c);
+            rg[i] = mb + r < m1 ? t : zero_chunk();
         }
-        MTN_UNROLL for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+        // taps are loaded under their validity condition (see the forward gather: measured faster than
+        // unconditional loads from clamped addresses + selects)
         const unsigned m = mb + pr;
-        if (m < m1) {
-            const unsigned b = m / ohw, rem = m - b * ohw;
-            const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
-            MTN_UNROLL for (int e = 0; e < 8; ++e) {
-                const int kk = pk0 + e;
-                const int iy = 2 * oy - 1 + kk / 9, ix = 2 * ox - 1 + (kk / 3) % 3;
-                if (kk < KK && iy >= 0 && iy < H && ix >= 0 && ix < W) rv[e] = x[(((long)b * 3 + kk % 3) * H + iy) * W + ix];
-                if (kk == ONE_K) rv[e] = 1.f;                     // slot 27 carries the constant 1
-            }
+        const unsigned mc = m < m1 ? m : m1 - 1;
+        const unsigned b = mc / ohw, rem = mc - b * ohw;
+        const int oy = (int)(rem / (unsigned)OW), ox = (int)(rem - (unsigned)oy * OW);
+        const float* xb = x + (long)b * 3 * H * W;
+        const bool live = m < m1;
+        MTN_UNROLL for (int e = 0; e < 8; ++e) {
+            const int kk = pk0 + e;
+            const int iy = 2 * oy + t_dy[e], ix = 2 * ox + t_dx[e];
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            const bool ok = live && kk < KK && iy == iyc && ix == ixc;
+            rv[e] = 0.f;
+            if (ok) rv[e] = xb[t_pl[e] + iy * W + ix];
+            if (kk == ONE_K) rv[e] = live ? 1.f : 0.f;
         }
     };
     auto stage = [&]() {
@@ -299,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restri
     if (m0 < m1) fetch(m0);
     for (unsigned mb = m0; mb < m1; mb += WPX) {
         stage();
-        __syncthreads();
+        MTN_BARRIER_LDS();
         if (mb + WPX < m1) fetch(mb + WPX);                       // in flight during this step's math
         MTN_UNROLL for (int i = 0; i < 4; ++i) {                  // pixel fragment i: pixel p = 16 i + (lane & 15)
             const int p = i * 16 + (lane & 15);
@@ -311,13 +409,13 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restri
             f32x4_t dz;
             MTN_UNROLL for (int r = 0; r < 4; ++r) {
                 const float z = raw[r] * k_sc[r] + k_sh[r];
-                const float d = act == MTN_ACT_SILU ? g[r] * silu_grad_(z) : g[r];
+                const float d = SILU ? g[r] * silu_grad_(z) : g[r];
                 s2[r] += d * (raw[r] * k_rs[r] + k_b2[r]);
                 dz[r] = d;
             }
             store4<T>(sD + p * PY + c0, dz);
         }
-        __syncthreads();
+        MTN_BARRIER_LDS();
         // contraction over the 64 pixels of the step: out[n][k], fragments id = 3*wid + q -> (n = id/2, k = id%2)
         MTN_UNROLL for (int ks = 0; ks < WPX / KI; ++ks) {
             MTN_UNROLL for (int q = 0; q < 3; ++q) {
@@ -327,7 +425,7 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restri
                 out3[q] = Mma<T>::mma(fa, ColFrag<T, TR>::load(sA + ks * KI * PA + kf * 16, PA, lane), out3[q]);
             }
         }
-        __syncthreads();
+        MTN_BARRIER_LDS();
     }
     float* out = partial + (long)blockIdx.x * BW_W;
     MTN_UNROLL for (int q = 0; q < 3; ++q) {
@@ -375,16 +473,16 @@ int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int 
     const int blocks = mtn_conv1_tiles(M);
     if (dtype == MTN_BF16) {
         const size_t lds = (size_t)PXB * (CO + 8) * 2;       // C tile (bf16) >= A + W tiles
-        MTN_LAUNCH((conv1_fwd_kernel<bf16_t, 0>), dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
-                   H, W, OH, OW, (const float*)nullptr, 0);
+        MTN_LAUNCH(conv1_fwd_kernel<bf16_t>, dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
+                   H, W, OH, OW);
     } else {
         const size_t lds = (size_t)PXB * (CO + 4) * 4;
 #ifndef MTN_EMU
         static MtnLdsAttr attr;
-        mtn_set_max_lds(attr, &conv1_fwd_kernel<float, 0>, lds);
+        mtn_set_max_lds(attr, &conv1_fwd_kernel<float>, lds);
 #endif
-        MTN_LAUNCH((conv1_fwd_kernel<float, 0>), dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
-                   W, OH, OW, (const float*)nullptr, 0);
+        MTN_LAUNCH(conv1_fwd_kernel<float>, dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
+                   W, OH, OW);
     }
     return mtn_check_launch("conv1_fwd");
 }
@@ -410,29 +508,38 @@ int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partia
 }
 
 // ---- fused stem -------------------------------------------------------------------------------------
+static int g_conv1_grid_cap = 0;       // debug key 11: cap on the fused kernels' grid (tests: several tiles per workgroup)
+void mtn_conv1_set_grid_cap(int n) { g_conv1_grid_cap = n > 0 ? n : 0; }
+
+template <class T, int MODE>
+static int conv1_fused_launch_t(const float* x, const void* w, void* y, float* stats, const float* ss, int act, int B, int H,
+                                int W, hipStream_t stream) {
+    const int OH = H / 2, OW = W / 2;
+    const long M = (long)B * OH * OW;
+    const int tiles = mtn_conv1_tiles(M);
+    // resident weights + the larger of the patch tile and (MODE 2) the output tile / (MODE 1) the reduction scratch
+    const size_t ea = (size_t)PXB * (32 * sizeof(T) + 16), ec = MODE == 2 ? (size_t)PXB * (CO * sizeof(T) + 16) : 2048;
+    const size_t lds = (size_t)CO * (32 * sizeof(T) + 16) + (ea > ec ? ea : ec);
+    // one round of resident workgroups, each walking tiles (prefetching the next one's taps)
+    const int per_cu = (int)(160 * 1024 / lds) < 8 ? (int)(160 * 1024 / lds) : 8;
+    int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    if (g_conv1_grid_cap && grid > g_conv1_grid_cap) grid = g_conv1_grid_cap;
+#ifndef MTN_EMU
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &conv1_fused_kernel<T, MODE>, lds);
+#endif
+    MTN_LAUNCH((conv1_fused_kernel<T, MODE>), dim3(grid), dim3(PXB), lds, stream, x, (const T*)w, (T*)y, stats, B, H, W, OH, OW, ss, act);
+    return mtn_check_launch("conv1_fused");
+}
+
 template <int MODE>
 static int conv1_fused_launch(const float* x, const void* w, void* y, float* stats, const float* ss, int act, int dtype,
                               int B, int H, int W, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv1: bad geometry %dx%dx%d", B, H, W);
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "conv1: bad dtype %d", dtype);
-    const int OH = H / 2, OW = W / 2;
-    const long M = (long)B * OH * OW;
-    MTN_REQUIRE(M * CO < (1L << 31), "conv1: tensor too large");
-    const int blocks = mtn_conv1_tiles(M);
-    if (dtype == MTN_BF16) {
-        const size_t lds = (size_t)PXB * (CO + 8) * 2;
-        MTN_LAUNCH((conv1_fwd_kernel<bf16_t, MODE>), dim3(blocks), dim3(PXB), lds, stream, x, (const bf16_t*)w, (bf16_t*)y, stats, B,
-                   H, W, OH, OW, ss, act);
-    } else {
-        const size_t lds = (size_t)PXB * (CO + 4) * 4;
-#ifndef MTN_EMU
-        static MtnLdsAttr attr;
-        mtn_set_max_lds(attr, &conv1_fwd_kernel<float, MODE>, lds);
-#endif
-        MTN_LAUNCH((conv1_fwd_kernel<float, MODE>), dim3(blocks), dim3(PXB), lds, stream, x, (const float*)w, (float*)y, stats, B, H,
-                   W, OH, OW, ss, act);
-    }
-    return mtn_check_launch("conv1_fused");
+    MTN_REQUIRE((long)B * (H / 2) * (W / 2) * CO < (1L << 31), "conv1: tensor too large");
+    return dtype == MTN_BF16 ? conv1_fused_launch_t<bf16_t, MODE>(x, w, y, stats, ss, act, B, H, W, stream)
+                             : conv1_fused_launch_t<float, MODE>(x, w, y, stats, ss, act, B, H, W, stream);
 }
 
 int mtn_conv1_stats_run(const float* x, const void* w, float* stats, int dtype, int B, int H, int W, hipStream_t stream) {
@@ -447,7 +554,8 @@ int mtn_conv1_bn_act_run(const float* x, const void* w, const float* scale_shift
     return conv1_fused_launch<2>(x, w, out, nullptr, scale_shift, act, dtype, B, H, W, stream);
 }
 
-static const int kBwdPx = 2048;
+static int kBwdPx = 3072;           // pixels per workgroup of the fused backward (debug key 12): 768 workgroups = one round at B = 256
+void mtn_conv1_set_bwd_px(int n) { kBwdPx = n >= 64 ? (n / 64) * 64 : 3072; }
 int mtn_conv1_bwd_blocks(long M) { return (int)((M + kBwdPx - 1) / kBwdPx); }
 int mtn_conv1_bwd_width(void) { return BW_W; }
 
@@ -461,12 +569,15 @@ int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const flo
     const int OH = H / 2, OW = W / 2;
     const long M = (long)B * OH * OW;
     const int blocks = mtn_conv1_bwd_blocks(M);
-    if (dtype == MTN_BF16)
-        MTN_LAUNCH((conv1_bwd_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, x, (const bf16_t*)w, (const bf16_t*)dout,
-                   scale_shift, mean_rstd, partial, B, H, W, OH, OW, kBwdPx, act);
-    else
-        MTN_LAUNCH((conv1_bwd_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, x, (const float*)w, (const float*)dout,
-                   scale_shift, mean_rstd, partial, B, H, W, OH, OW, kBwdPx, act);
+#define MTN_CONV1_BWD(T, TR, SILU)                                                                                          \
+    MTN_LAUNCH((conv1_bwd_kernel<T, TR, SILU>), dim3(blocks), dim3(256), 0, stream, x, (const T*)w, (const T*)dout, scale_shift, \
+               mean_rstd, partial, B, H, W, OH, OW, kBwdPx)
+    if (dtype == MTN_BF16) {
+        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(bf16_t, true, true); else MTN_CONV1_BWD(bf16_t, true, false);
+    } else {
+        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(float, false, true); else MTN_CONV1_BWD(float, false, false);
+    }
+#undef MTN_CONV1_BWD
     int rc = mtn_check_launch("conv1_bwd");
     if (rc) return rc;
     float* sums = partial + (long)mtn_reduce_rows_needed(blocks) * BW_W;     // after the slab and its folding scratch

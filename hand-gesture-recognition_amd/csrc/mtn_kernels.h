@@ -146,3 +146,5 @@ void mtn_igemm_set_window_limit(int kb);
 int mtn_igemm_read_stamps(void* dst, size_t bytes);
 void mtn_wgrad_set_tile(int t);
 void mtn_wgrad_set_slots(int n);
+void mtn_conv1_set_grid_cap(int n);
+void mtn_conv1_set_bwd_px(int n);

@@ -36,6 +36,22 @@ static inline void mtn_set_max_lds(MtnLdsAttr& st, K kern, size_t bytes) {
 }
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() is a fence + barrier and
+// waits vmcnt(0) first, which drains a register prefetch of global loads at every barrier of a
+// loop (the prefetch then hides nothing); this form waits for the wave's LDS operations and leaves
+// global loads in flight (cdna_hip_programming.md section 5, "Pipelining across barriers").  Use it
+// only where the data handed over at the barrier lives in LDS.
+#ifdef MTN_EMU
+#define MTN_BARRIER_LDS() __syncthreads()
+#else
+#define MTN_BARRIER_LDS()                                         \
+    do {                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();                             \
+        asm volatile("" ::: "memory");                            \
+    } while (0)
+#endif
+
 // status codes of the C ABI (include/mtn.h)
 #define MTN_OK 0
 #define MTN_ERR_BAD_ARG 1

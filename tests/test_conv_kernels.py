@@ -259,11 +259,21 @@ def test_conv1_fwd_wgrad(be, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 16, 16), (1, 12, 20), (3, 8, 8)])
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 0), (1, 12, 20, 0), (3, 8, 8, 0), (3, 32, 32, 2)])
 def test_conv1_fused_stem(be, dtype, cfg):
     """stats-only pass, conv+BN+SiLU pass and the one-pass backward (recomputed conv, closed-form BN
     backward, weight gradient from the pixel contraction) against torch autograd of SiLU(BN(conv(x)))."""
-    B, H, W = cfg
+    from hand_gesture_recognition_amd import lib
+    B, H, W, grid_cap = cfg
+    d = be.device
+    lib.call("mtn_debug_set", 11, grid_cap)      # > 0: fewer workgroups than tiles -> the tile loop + tap prefetch run
+    try:
+        _conv1_fused_case(be, dtype, B, H, W)
+    finally:
+        lib.call("mtn_debug_set", 11, 0)
+
+
+def _conv1_fused_case(be, dtype, B, H, W):
     d = be.device
     x = _rand((B, 3, H, W), torch.float32, 51)
     w = (_rand((64, 3, 3, 3), torch.float32, 52) / 27 ** 0.5)

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--wgrad_tile", type=int, default=0)
     ap.add_argument("--igemm_dbg", type=int, default=0)
     ap.add_argument("--wgrad_slots", type=int, default=0)
+    ap.add_argument("--conv1_px", type=int, default=0)
     ap.add_argument("--win_limit", type=int, default=0, help="window-mode LDS limit in KB (default 53)")
     ap.add_argument("--lib", default="", help="A/B: load this build of the library instead of libmtn_hip.so")
     a = ap.parse_args()
@@ -51,7 +52,10 @@ def main():
     _lib.call("mtn_debug_set", 6, a.igemm_tile)
     _lib.call("mtn_debug_set", 7, a.wgrad_tile)
     _lib.call("mtn_debug_set", 8, a.igemm_dbg)
-    _lib.call("mtn_debug_set", 10, a.wgrad_slots)
+    try:
+        _lib.call("mtn_debug_set", 10, a.wgrad_slots)
+    except RuntimeError:
+        pass
     if a.win_limit:
         _lib.call("mtn_debug_set", 9, a.win_limit)
     dev = torch.device("cuda:0")
@@ -66,6 +70,33 @@ def main():
         ("s3.cv1", 12, 12, 512, 512, 1, 1), ("s3.3x3", 12, 12, 256, 256, 3, 1), ("s3.cv4", 12, 12, 1024, 512, 1, 1),
         ("proj", 12, 12, 512, 256, 1, 1),
     ]
+    if not a.filter or a.filter in "conv1":
+        H = W = 192
+        x = torch.randn(B, 3, H, W, device=dev)
+        w = (torch.randn(64, 3, 3, 3, device=dev) / 27 ** 0.5).to(dt)
+        tiles = ops.conv1_stats_tiles(B, H, W)
+        stats = torch.empty(ops.slab_rows(tiles), 2, 64, device=dev)
+        ss, mr = torch.randn(2, 64, device=dev), torch.rand(2, 64, device=dev) + 0.5
+        out = torch.empty(B, H // 2, W // 2, 64, device=dev, dtype=dt)
+        dout = torch.randn(B, H // 2, W // 2, 64, device=dev).to(dt)
+        dg, db, dw = torch.empty(64, device=dev), torch.empty(64, device=dev), torch.empty(64, 3, 3, 3, device=dev)
+        xb, ob = x.numel() * 4, out.numel() * esz
+        t = timeit(lambda: ops.conv1_stats(x, w, stats))
+        print(f"conv1.stats    {t*1e6:9.1f} us  {xb/t/1e9:7.0f} GB/s")
+        t = timeit(lambda: ops.conv1_bn_act(x, w, ss, out, ops.ACT_SILU))
+        print(f"conv1.bn_act   {t*1e6:9.1f} us  {(xb+ob)/t/1e9:7.0f} GB/s")
+        for px in (a.conv1_px and [a.conv1_px] or [1024, 2048, 3072, 4096]):
+            try:
+                _lib.call("mtn_debug_set", 12, px)
+            except RuntimeError:
+                pass                                   # an older build without the key
+            part = torch.empty(*ops.conv1_bwd_partial_shape(B, H, W), device=dev)
+            t = timeit(lambda: ops.conv1_bwd(x, w, dout, ss, mr, part, dg, db, dw, ops.ACT_SILU))
+            print(f"conv1.bwd px/wg={px:5d} {t*1e6:9.1f} us  {(xb+ob)/t/1e9:7.0f} GB/s")
+        try:
+            _lib.call("mtn_debug_set", 12, 0)
+        except RuntimeError:
+            pass
     for name, H, W, Cin, Cout, k, s in convs:
         if a.filter and a.filter not in "conv_fwd." + name:
             continue
