@@ -89,7 +89,9 @@ static int conv_wgrad_args(WgradArgs& p, int dtype, int B, int H, int W, int Cin
     p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.M = B * p.OH * p.OW; p.N = Cout; p.K = ksize * ksize * Cin;
     if (Cout % 64 != 0 || Cin % 64 != 0) { mtn_set_error("wgrad: Cout=%d, Cin=%d must be multiples of 64", Cout, Cin); return 1; }
-    p.splits = mtn_wgrad_splits(p.M, p.N, p.K, Cin, dtype, &p.rows_per_split);
+    p.win = mtn_wgrad3_ok(dtype, H, W, ksize, stride);
+    if (p.win) p.splits = mtn_wgrad3_splits(B, H, W, p.N, Cin, dtype, &p.rows_per_split);
+    else p.splits = mtn_wgrad_splits(p.M, p.N, p.K, Cin, dtype, &p.rows_per_split);
     return 0;
 }
 
@@ -294,6 +296,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 10) { mtn_wgrad_set_slots(value); return MTN_OK; }
     if (key == 11) { mtn_conv1_set_grid_cap(value); return MTN_OK; }
     if (key == 12) { mtn_conv1_set_bwd_px(value); return MTN_OK; }
+    if (key == 13) { mtn_wgrad_set_win(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

@@ -41,7 +41,8 @@ struct WgradArgs {
     float* dW;                    // [N][Cin][KH][KW] f32 (reference OIHW layout)
     int B, H, W, Cin, OH, OW, KH, KW, stride, pad;
     int M, N, K;
-    int splits, rows_per_split;
+    int splits, rows_per_split;   // win: split of the PADDED SLOT axis, rows_per_split = slots per split
+    int win;                      // 3x3 stride-1 window kernel (wgrad3_kernel)
     unsigned y_bytes, x_bytes;    // filled by mtn_wgrad_run: byte extents of dY / X (buffer descriptors)
     unsigned magic_ow, magic_oh;  // filled by mtn_wgrad_run: multiply-high divisors of the pixel walk
 };
@@ -146,5 +147,8 @@ void mtn_igemm_set_window_limit(int kb);
 int mtn_igemm_read_stamps(void* dst, size_t bytes);
 void mtn_wgrad_set_tile(int t);
 void mtn_wgrad_set_slots(int n);
+void mtn_wgrad_set_win(int on);
+int mtn_wgrad3_ok(int dtype, int H, int W, int ksize, int stride);
+int mtn_wgrad3_splits(int B, int H, int W, int N, int Cin, int dtype, int* slots_per_split);
 void mtn_conv1_set_grid_cap(int n);
 void mtn_conv1_set_bwd_px(int n);

@@ -232,9 +232,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     constexpr int FM = WM / 16, FN = WN / 16;
     static_assert(BMR % (RPBY * NW) == 0 && BMR % (RPBX * NW) == 0, "DMA mapping");
 
+    // (One dynamic array with a runtime stage offset: hipcc then cannot tell the stage being filled from
+    // the stage being read and waits vmcnt(0) before the first fragment read after every DMA issue, i.e.
+    // a workgroup does not overlap its own DMA with its own MFMAs -- the 2..4 co-resident workgroups
+    // overlap each other instead.  Two distinct __shared__ stages remove that wait (wgrad3_kernel below
+    // does it), but here it measured SLOWER on 10 of 13 layers (conv2 +24 %, down1/2 +12 %, cv4 +17 %):
+    // the in-flight DMA then contends with the fragment reads of the same workgroup.)
     MTN_DYN_SMEM(smem);
-    T* const sY = reinterpret_cast<T*>(smem);          // [2][BMR][BN]
-    T* const sX = sY + 2 * BMR * BN;                   // [2][BMR][BC]
+    T* const sStage0 = reinterpret_cast<T*>(smem);               // [BMR][BN] dY then [BMR][BC] X
+    T* const sStage1 = sStage0 + BMR * (BN + BC);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
 
@@ -282,10 +288,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
         xchunk[i] = Swz<T, BC>::fetch_chunk(xrow[i], lane % CPRX);
         xpos[i] = pointwise ? PixelPos{0, 0, 0} : pixel_of(m_begin + xrow[i], p);
     }
-    auto dma_tiles = [&](int st, int stage) {
+    auto dma_tiles = [&](int st, T* stage) {
         const long mb = m_begin + (long)st * BMR;
-        char* y = reinterpret_cast<char*>(sY + stage * BMR * BN);
-        char* x = reinterpret_cast<char*>(sX + stage * BMR * BC);
+        char* y = reinterpret_cast<char*>(stage);
+        char* x = reinterpret_cast<char*>(stage + BMR * BN);
         MTN_UNROLL for (int i = 0; i < IY; ++i) {
             const long m = mb + yrow[i];
             const unsigned off = (unsigned)(m * p.lddy + n0 + ychunk[i] * VEC) * (unsigned)sizeof(T);
@@ -310,13 +316,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     MTN_UNROLL for (int i = 0; i < FM; ++i)
         MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
 
-    if (steps > 0) dma_tiles(0, 0);
-    __syncthreads();
-    for (int st = 0; st < steps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < steps) dma_tiles(st + 1, cur ^ 1);
-        const T* y = sY + cur * BMR * BN;
-        const T* x = sX + cur * BMR * BC;
+    auto step = [&](int st, const T* rd, T* wr) {
+        if (st + 1 < steps) dma_tiles(st + 1, wr);
+        const T* y = rd;
+        const T* x = rd + BMR * BN;
         MTN_UNROLL for (int ks = 0; ks < BMR / KI; ++ks) {
             typename Mma<T>::Frag fa[FM], fb[FN];
             MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFragS<T, BN>::load(y, ks * KI, wm * WM + i * 16, lane);
@@ -325,6 +328,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
                 MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
         }
         __syncthreads();
+    };
+    if (steps > 0) dma_tiles(0, sStage0);
+    __syncthreads();
+    for (int st = 0; st < steps; st += 2) {
+        step(st, sStage0, sStage1);
+        if (st + 1 < steps) step(st + 1, sStage1, sStage0);
     }
     float* __restrict__ out = p.partial + (long)split * p.N * p.K;
     MTN_UNROLL for (int i = 0; i < FM; ++i)
@@ -334,6 +343,191 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
                 const int k = kcol0 + wn * WN + j * 16 + 4 * (lane >> 4);
                 store4<float>(out + (long)n * p.K + k, acc[i][j]);
             }
+}
+
+// ---- 3x3, stride 1: all nine taps from ONE window of the input -------------------------------------
+// The tiles above re-stream dY and the tap-shifted X once per tap: nine times the bytes through the
+// L2 -> LDS path for the same FLOPs, and that path (64 B/clk/CU) is what bounds them.  Here a
+// workgroup owns dW[64 n][9 taps][64 ci] (36 accumulator fragments per wave) and walks the pixel axis
+// in PADDED SLOT coordinates: every image row gets one extra (zero) slot and every image one extra
+// (zero) row, so that
+//     slot s = (b*(H+1) + y)*(W+1) + x,      tap (kh, kw) of slot s reads slot s + (kh-1)*(W+1) + (kw-1)
+// and a tap that leaves the image lands on a zero slot: no masks, no per-tap validity arithmetic --
+// the zero slots are produced by the LDS-DMA's out-of-range zero fill, for dY as well (a zero dY slot
+// times anything is nothing).  Per step a workgroup stages KS slots of dY[:, n-tile] and the
+// KS + 2(W+2) slots of X[:, ci-tile] around them (lane-linear, swizzled on the source chunk like the
+// tiles above) and every tap reads its operand fragments down the slot axis at a ROW OFFSET of that
+// one window: the offsets (swizzle included) are nine constants per lane, the K-sub-step is an
+// immediate.  Bytes through the DMA path per FLOP: 1/3.3 (W = 48) .. 1/4.5 (W = 12) of the per-tap
+// tiles; cost: (W+1)(H+1)/(WH) - 1 = 4 % (48^2) .. 17 % (12^2) of MFMA work on zero slots.
+template <class T> struct Wg3 {
+    static constexpr int KS = sizeof(T) == 2 ? 128 : 64;         // slots per step
+    static constexpr int VEC = 16 / (int)sizeof(T);
+    static constexpr int CPR = 64 / VEC;                          // 16-byte slots per 64-channel row
+    static constexpr int RPB = 64 / CPR;                          // rows per 1 KiB DMA piece (8 bf16 / 4 f32)
+    static constexpr int MAXW = sizeof(T) == 2 ? 96 : 48;         // widest feature map whose two window stages fit 160 KB
+    static constexpr int STAGE = (2 * KS + 2 * (MAXW + 2) + RPB) * 64;   // elements: dY [KS][64] + window [KS + 2(W+2)][64]
+};
+
+// 8 waves: wave = (input-channel fragment w & 3, half of the 64 output channels w >> 2), 18 accumulator
+// fragments each; ONE workgroup per CU with two LDS stages: the DMA of step t+1 is issued piece by
+// piece between the K-sub-steps of step t.  (One workgroup per CU, not two: every workgroup writes its
+// 64 x 576 f32 partial tile to the slab, so the slab -- written here, read back by wgrad_reduce -- is
+// 147 KB x workgroups; at 512 workgroups that was 75 MB per layer, as many bytes as the operands.)
+template <class T>
+__global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
+    constexpr int KS = Wg3<T>::KS, VEC = Wg3<T>::VEC, CPR = Wg3<T>::CPR, RPB = Wg3<T>::RPB;
+    constexpr int KI = Mma<T>::KI;
+    constexpr int SUB = 32;                                       // slots per K-sub-step of the MFMA loop
+    constexpr int NSUB = KS / SUB;
+    constexpr int NW = 8;
+    typedef Swz<T, 64> SW;
+    // The two LDS stages are two DISTINCT __shared__ objects, and the step loop below is unrolled by
+    // two so that every LDS-DMA names one object and every fragment read the other.  With one array
+    // and a runtime stage offset hipcc cannot tell them apart and puts `s_waitcnt vmcnt(0)` in front
+    // of the first fragment read after every DMA issue (an LDS-DMA is an LDS write to the compiler):
+    // the prefetch then hides nothing (cdna_hip_programming.md section 5, trap 4a).
+    __shared__ __attribute__((aligned(16))) T sStage0[Wg3<T>::STAGE];
+    __shared__ __attribute__((aligned(16))) T sStage1[Wg3<T>::STAGE];
+    const int W1 = p.W + 1, H1 = p.H + 1, HALO = W1 + 1;
+    const int WR = (KS + 2 * HALO + RPB - 1) / RPB * RPB;         // window rows, whole DMA pieces
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cf = wid & 3, nh = wid >> 2;
+
+    // (tile, split): the tiles of one split stream the same rows -> keep them on one XCD group
+    const int tiles_n = p.N / 64, tiles = tiles_n * (p.Cin / 64);
+    int tile, split;
+    {
+        const int L = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        split = lin / tiles;
+        tile = lin - split * tiles;
+    }
+    const int n0 = (tile % tiles_n) * 64, c0 = (tile / tiles_n) * 64;
+    const unsigned S = (unsigned)p.B * H1 * W1;                   // padded slots
+    const unsigned s_begin = (unsigned)split * p.rows_per_split;
+    unsigned s_end = s_begin + p.rows_per_split;
+    if (s_end > S) s_end = S;
+    const int steps = s_begin < s_end ? (int)((s_end - s_begin + KS - 1) / KS) : 0;
+
+    const BufDesc bufY = make_buf(p.dY, p.y_bytes), bufX = make_buf(p.X, p.x_bytes);
+    // byte offset of (slot s, 16-byte chunk) in a pixel-major tensor, or the zero-fill offset
+    auto src = [&](unsigned s, int ld, int col0, int chunk) -> unsigned {
+        const unsigned R = __umulhi(s, p.magic_ow), col = s - R * (unsigned)W1;       // s / W1
+        const unsigned b = __umulhi(R, p.magic_oh), y = R - b * (unsigned)H1;         // R / H1
+        const unsigned px = (b * (unsigned)p.H + y) * (unsigned)p.W + col;
+        const bool ok = s < S && col < (unsigned)p.W && y < (unsigned)p.H;
+        return ok ? (px * (unsigned)ld + (unsigned)(col0 + chunk * VEC)) * (unsigned)sizeof(T) : 0xFFFFFFF0u;
+    };
+    const int prow = lane / CPR, pslot = lane % CPR;              // this lane's row / 16-byte slot inside a DMA piece
+    const int PY = KS / RPB, PT = PY + WR / RPB;                  // pieces of the dY tile / of the whole stage
+    // piece q of the stage that starts at slot s0 (q < PY: dY rows, else window rows)
+    auto dma_piece = [&](int q, unsigned s0, T* stage) {
+        char* base = reinterpret_cast<char*>(stage);
+        if (q < PY) {
+            const int row = q * RPB + prow;
+            buf_glds16(bufY, src(s0 + row, p.lddy, n0, SW::fetch_chunk(row, pslot)), base + q * 1024);
+        } else if (q < PT) {
+            const int row = (q - PY) * RPB + prow;
+            buf_glds16(bufX, src(s0 - HALO + row, p.ldx, c0, SW::fetch_chunk(row, pslot)), base + q * 1024);
+        }
+    };
+
+    // accumulators: [tap][n fragment of this wave's half]
+    f32x4_t acc[9][2];
+    MTN_UNROLL for (int t = 0; t < 9; ++t) { acc[t][0] = zero4(); acc[t][1] = zero4(); }
+    // operand fragment offsets (elements) at K-sub-step 0: rows advance by SUB per sub-step, which
+    // leaves the swizzle (a function of row bits 0..3) unchanged -> the sub-step is an address immediate
+    int yoff[2][2], xoff[9][2];
+    if (sizeof(T) == 2) {
+        const int g = lane >> 4, i16 = lane & 15;
+        const int r0 = 8 * g + (i16 >> 2), cc = 4 * (i16 & 3);
+        MTN_UNROLL for (int i = 0; i < 2; ++i) {
+            yoff[i][0] = SW::off(r0, (nh * 2 + i) * 16 + cc);
+            yoff[i][1] = SW::off(r0 + 4, (nh * 2 + i) * 16 + cc);
+        }
+        MTN_UNROLL for (int t = 0; t < 9; ++t) {
+            const int sh = HALO + (t / 3 - 1) * W1 + (t % 3 - 1);
+            xoff[t][0] = KS * 64 + SW::off(r0 + sh, cf * 16 + cc);
+            xoff[t][1] = KS * 64 + SW::off(r0 + 4 + sh, cf * 16 + cc);
+        }
+    }
+    auto frag = [&](const T* tile, int e0, int e1, int row, int col) -> typename Mma<T>::Frag {
+        if constexpr (sizeof(T) == 2) {
+            (void)row; (void)col;
+            const bf16_t* q0 = reinterpret_cast<const bf16_t*>(tile) + e0;
+            const bf16_t* q1 = reinterpret_cast<const bf16_t*>(tile) + e1;
+            bf16x8_t f;
+#ifdef MTN_EMU
+            emu::u16x4 a = emu::ds_read_tr16_b64(q0), b = emu::ds_read_tr16_b64(q1);
+            MTN_UNROLL for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+#else
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
+            const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(q0));
+            const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(q1));
+            f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+            return f;
+        } else {
+            (void)e0; (void)e1;
+            return ColFragS<float, 64>::load(reinterpret_cast<const float*>(tile), row, col, lane);
+        }
+    };
+
+    // one step: multiply the stage `rd` while the DMA of step st+1 lands in `wr`
+    auto step = [&](int st, const T* rd, T* wr) {
+        if (st + 1 < steps) {
+            const unsigned s_next = s_begin + (unsigned)(st + 1) * KS;
+            for (int q = wid; q < PT; q += NW) dma_piece(q, s_next, wr);
+        }
+        if constexpr (sizeof(T) == 2) {
+            // fragments of sub-step j+1 are read while the MFMAs of sub-step j issue (two register sets)
+            typename Mma<T>::Frag fy[2][2], fx[2][9];
+            auto load_sub = [&](int j, int set) {
+                MTN_UNROLL for (int i = 0; i < 2; ++i) fy[set][i] = frag(rd, yoff[i][0] + j * SUB * 64, yoff[i][1] + j * SUB * 64, 0, 0);
+                MTN_UNROLL for (int t = 0; t < 9; ++t) fx[set][t] = frag(rd, xoff[t][0] + j * SUB * 64, xoff[t][1] + j * SUB * 64, 0, 0);
+            };
+            load_sub(0, 0);
+            MTN_UNROLL for (int j = 0; j < NSUB; ++j) {
+                if (j + 1 < NSUB) load_sub(j + 1, (j + 1) & 1);
+                MTN_SCHED_FENCE();
+                MTN_UNROLL for (int t = 0; t < 9; ++t)
+                    MTN_UNROLL for (int i = 0; i < 2; ++i) acc[t][i] = Mma<T>::mma(fx[j & 1][t], fy[j & 1][i], acc[t][i]);
+                MTN_SCHED_FENCE();
+            }
+        } else {
+            MTN_UNROLL for (int j = 0; j < NSUB; ++j) {
+                MTN_UNROLL for (int kk = 0; kk < SUB / KI; ++kk) {
+                    const int k0 = j * SUB + kk * KI;
+                    typename Mma<T>::Frag fy[2];
+                    MTN_UNROLL for (int i = 0; i < 2; ++i) fy[i] = frag(rd, 0, 0, k0, (nh * 2 + i) * 16);
+                    MTN_UNROLL for (int t = 0; t < 9; ++t) {
+                        const int sh = HALO + (t / 3 - 1) * W1 + (t % 3 - 1);
+                        const typename Mma<T>::Frag fx = frag(rd + KS * 64, 0, 0, k0 + sh, cf * 16);
+                        MTN_UNROLL for (int i = 0; i < 2; ++i) acc[t][i] = Mma<T>::mma(fx, fy[i], acc[t][i]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                          // own DMA landed (vmcnt 0) + everyone is done with `rd`
+    };
+    if (steps > 0)
+        for (int q = wid; q < PT; q += NW) dma_piece(q, s_begin, sStage0);
+    __syncthreads();
+    for (int st = 0; st < steps; st += 2) {
+        step(st, sStage0, sStage1);
+        if (st + 1 < steps) step(st + 1, sStage1, sStage0);
+    }
+    // partial tile -> slab[split][n][tap*Cin + ci]: the X fragment is the MFMA's row operand, so a lane's
+    // quad is 4 consecutive ci of one n
+    float* __restrict__ out = p.partial + (long)split * p.N * p.K;
+    MTN_UNROLL for (int t = 0; t < 9; ++t)
+        MTN_UNROLL for (int i = 0; i < 2; ++i) {
+            const int n = n0 + (nh * 2 + i) * 16 + (lane & 15);
+            const int k = t * p.Cin + c0 + cf * 16 + 4 * (lane >> 4);
+            store4<float>(out + (long)n * p.K + k, acc[t][i]);
+        }
 }
 
 // dW_oihw[o][ci][kh][kw] = sum_s partial[s][o][(kh*KW+kw)*Cin + ci]; block = 4 split lanes x 64 elements
@@ -383,9 +577,44 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
     return mtn_check_launch("wgrad_dma");
 }
 
+template <class T>
+int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
+    constexpr int KS = Wg3<T>::KS, RPB = Wg3<T>::RPB;
+    const int halo = p.W + 2;
+    const int wr = (KS + 2 * halo + RPB - 1) / RPB * RPB;
+    MTN_REQUIRE((KS + wr) * 64 <= Wg3<T>::STAGE, "wgrad3: window of a %d-wide map does not fit", p.W);
+    const int tiles = (p.N / 64) * (p.Cin / 64);
+    MTN_LAUNCH(wgrad3_kernel<T>, dim3(tiles * p.splits), dim3(512), 0, stream, p);
+    return mtn_check_launch("wgrad3");
+}
+
 }  // namespace
 
 static int g_use_tr16 = 1;
+static int g_wgrad3 = 1;         // debug key 13: 0 = per-tap tiles for 3x3 stride-1 layers too
+void mtn_wgrad_set_win(int on) { g_wgrad3 = on; }
+
+// the window kernel serves 3x3 / stride 1 / pad 1 layers whose two window stages fit the LDS of a CU
+int mtn_wgrad3_ok(int dtype, int H, int W, int ksize, int stride) {
+    if (!g_wgrad3 || ksize != 3 || stride != 1) return 0;
+    (void)H;
+    return W <= (dtype == MTN_BF16 ? 96 : 48);                    // Wg3<T>::MAXW
+}
+
+// split of the padded slot axis: one workgroup per CU
+int mtn_wgrad3_splits(int B, int H, int W, int N, int Cin, int dtype, int* slots_per_split) {
+    const int ks = dtype == MTN_BF16 ? 128 : 64;
+    const long S = (long)B * (H + 1) * (W + 1);
+    const long tiles = (long)(N / 64) * (Cin / 64);
+    long splits = (g_wgrad_slots > 0 ? g_wgrad_slots : 256) / tiles;
+    if (splits < 1) splits = 1;
+    const long max_splits = (S + ks - 1) / ks;
+    if (splits > max_splits) splits = max_splits;
+    long sps = (S + splits - 1) / splits;
+    sps = (sps + ks - 1) / ks * ks;
+    *slots_per_split = (int)sps;
+    return (int)((S + sps - 1) / sps);
+}
 void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
 void mtn_wgrad_set_slots(int n) { g_wgrad_slots = n > 0 ? n : 0; }
@@ -446,8 +675,10 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.N % 64 == 0 && p.Cin % 64 == 0, "wgrad: N=%d and Cin=%d must be multiples of 64", p.N, p.Cin);
     MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "wgrad: K mismatch");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "wgrad: M mismatch");
-    MTN_REQUIRE(p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M,
+    MTN_REQUIRE(p.win || (p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M),
                 "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
+    MTN_REQUIRE(!p.win || (p.splits >= 1 && (long)p.splits * p.rows_per_split >= (long)p.B * (p.H + 1) * (p.W + 1)),
+                "wgrad3: bad split (%d x %d slots)", p.splits, p.rows_per_split);
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
     MTN_REQUIRE((p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) ||
                     (((long)p.M + 128) * p.OW < (1L << 32) && ((long)p.M / p.OW + 128) * p.OH < (1L << 32)),
@@ -461,7 +692,14 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
         p.x_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.ldx + p.Cin) * esz);
     }
     int rc;
-    if (dtype == MTN_BF16) rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
+    if (p.win) {
+        const unsigned w1 = (unsigned)p.W + 1u, h1 = (unsigned)p.H + 1u;
+        MTN_REQUIRE(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W, "wgrad3: 3x3 stride-1 layers only");
+        MTN_REQUIRE(((long)p.B * h1 * w1 + 4096) * w1 < (1L << 32), "wgrad3: too many slots for the multiply-high decode");
+        p.magic_ow = (unsigned)(0x100000000ull / w1) + 1u;        // slot / (W+1)
+        p.magic_oh = (unsigned)(0x100000000ull / h1) + 1u;        // row / (H+1)
+        rc = dtype == MTN_BF16 ? launch_wgrad3<bf16_t>(p, stream) : launch_wgrad3<float>(p, stream);
+    } else if (dtype == MTN_BF16) rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
     else rc = wgrad_dispatch<float, false>(p, stream);
     if (rc) return rc;
     const long total = (long)p.N * p.K;

@@ -203,6 +203,40 @@ def test_conv_wgrad(be, dtype, tr16, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    (3, 12, 20, 64, 64, 0),          # non-square, one tile
+    (2, 7, 5, 128, 64, 0),           # odd sizes, two input-channel tiles
+    (3, 12, 20, 64, 128, 2),         # two workgroups per tile only: several window steps per workgroup
+    (1, 24, 24, 64, 64, 1),          # one workgroup walks the whole (padded) pixel axis
+])
+def test_conv_wgrad_window_kernel(be, dtype, cfg):
+    """3x3 / stride 1 through the nine-taps-from-one-window kernel (padded slot coordinates): against
+    torch, and against the per-tap tiles it replaces."""
+    from hand_gesture_recognition_amd import lib
+    B, H, W, Cin, Cout, slots = cfg
+    x = _rand((B, H, W, Cin), dtype, 61)
+    w = torch.zeros((Cout, Cin, 3, 3), requires_grad=True)
+    yref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 1)
+    dy = _rand((B, H, W, Cout), dtype, 62)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    res = []
+    for win in (1, 0):
+        lib.call("mtn_debug_set", 13, win)
+        lib.call("mtn_debug_set", 10, slots if win else 0)
+        try:
+            ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 3, 1) // 4, device=be.device)
+            dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=be.device)
+            ops.conv_wgrad(x.to(be.device), dy.to(be.device), dw, ws, 3, 1)
+            be.sync()
+            res.append(dw.cpu())
+        finally:
+            lib.call("mtn_debug_set", 13, 1)
+            lib.call("mtn_debug_set", 10, 0)
+    assert rel_err(res[0], w.grad) < tol(dtype, 1e-4, 1e-2)
+    assert rel_err(res[0], res[1]) < tol(dtype, 1e-5, 1e-5)       # same products, f32 sums in another order
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_wgrad_large_m(be, dtype):
     M, K, N = 300, 256, 64
     x, dy = _rand((M, K), dtype, 14), _rand((M, N), dtype, 15)
