@@ -10,6 +10,7 @@
 // Loss (libs/loss.py:4-40, train.py:63-64,75): total = 0.001 * CrossEntropy(mean) + JointsMSE,
 // JointsMSE == 0.5 * mean_{b,j,p} (w_bj (p - t))^2; the kernel emits the three scalars and both
 // gradients (dlogits, dheatmap) in one pass.
+#include <type_traits>
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
@@ -623,6 +624,304 @@ __global__ __launch_bounds__(256) void pose_fwd_mma_kernel(const T* __restrict__
     }
 }
 
+// ---- row-streaming pose head (round 2) ------------------------------------------------------------
+// The kernels above cut an image into 32-channel chunks x 96-pixel tiles and pay 3-4 workgroup
+// barriers per (chunk, tile) for a few hundred cycles of work between them; they ran 5-10x above
+// the head's memory traffic.  Here a workgroup owns ALL 256 channels of an image (a band of its
+// output rows in the forward pass) and walks the output rows:
+//   Y[sx][c]  = (1-wy) S[y0][sx][c] + wy S[y1][sx][c]        thread = channel, global -> LDS (f32, own column)
+//   R[ox][c]  = relu((1-wx) Y[x0][c] + wx Y[x1][c])          thread = channel, two-register window over x0
+//   hm[j][ox] = sum_c R[ox][c] W[j][c] + bias[j]             MFMA, K = 256
+// The interpolation stays exact f32 arithmetic on the VALU (the sign of u is the ReLU mask that
+// forward and backward must agree on): 4 FLOP per element against the dense x-interpolation matrix
+// product (2 w FLOP per element on the 1/16-rate f32 MFMA) of the kernels above.
+// The map width is a template parameter: the x loop is fully unrolled, so the y-mixed row lives in
+// registers and every x tap index / weight is a literal (a first version read them from LDS tables
+// in a rolled loop: three dependent LDS round trips per output element, 10x slower).
+template <class T, int WT>
+__global__ __launch_bounds__(256) void pose_fwd_row_kernel(const T* __restrict__ tok, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ hm, int h,
+                                                           int J, int rows_per_band) {
+    constexpr int PW = DIM + 16 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
+    constexpr int w = WT, OW = 4 * WT, OWM = (OW + 15) & ~15;
+    MTN_DYN_SMEM(smem);
+    const int hw = h * w, OH = 4 * h;
+    T* sW = reinterpret_cast<T*>(smem);                          // [32][PW]
+    T* sR = sW + 32 * PW;                                        // [OWM][PW]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_band;
+    int r_end = r_begin + rows_per_band;
+    if (r_end > OH) r_end = OH;
+    for (int i = tid; i < 32 * (DIM / 4); i += 256) {
+        const int j = i / (DIM / 4), c = (i - j * (DIM / 4)) * 4;
+        f32x4_t v = zero4();
+        if (j < J) v = *reinterpret_cast<const f32x4_t*>(W + j * DIM + c);
+        store4<T>(sW + j * PW + c, v);
+    }
+    for (int i = tid; i < (OWM - OW) * DIM; i += 256) sR[(OW + i / DIM) * PW + (i % DIM)] = from_f<T>(0.f);   // M padding rows
+    const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + tid;   // this thread's channel
+    const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
+    const int nfr = (OWM / 16) * 2;                               // head fragments (pixels x joint halves)
+    // the two token rows of the current y interval stay in registers: four output rows share them
+    float t0[WT], t1[WT];
+    int cur_y0 = -1;
+    for (int oy = r_begin; oy < r_end; ++oy) {
+        __syncthreads();                                          // setup / the previous row's MFMAs are done with sR
+        const Lerp ly = lerp_coord(oy, h, OH);
+        const float wy = ly.w1;
+        if (ly.i0 != cur_y0) {                                    // wave-uniform
+            const T* s0 = base + (long)ly.i0 * w * DIM;
+            const T* s1 = base + (long)ly.i1 * w * DIM;
+            MTN_UNROLL for (int sx = 0; sx < WT; ++sx) { t0[sx] = to_f<T>(s0[(long)sx * DIM]); t1[sx] = to_f<T>(s1[(long)sx * DIM]); }
+            cur_y0 = ly.i0;
+        }
+        float ya[WT];
+        MTN_UNROLL for (int sx = 0; sx < WT; ++sx) ya[sx] = (1.f - wy) * t0[sx] + wy * t1[sx];
+        MTN_UNROLL for (int ox = 0; ox < OW; ++ox) {
+            const Lerp lx = lerp_coord(ox, WT, OW);               // literals after unrolling
+            const float u = (1.f - lx.w1) * ya[lx.i0] + lx.w1 * ya[lx.i1];
+            sR[ox * PW + tid] = from_f<T>(u > 0.f ? u : 0.f);
+        }
+        __syncthreads();
+        for (int f = wid; f < nfr; f += 4) {                      // hm[j][px] : the weight fragment is the row operand
+            const int pf = f >> 1, jf = f & 1;
+            f32x4_t acc = zero4();
+            MTN_UNROLL for (int k0 = 0; k0 < DIM; k0 += KI)
+                acc = Mma<T>::mma(Mma<T>::load(sW + (jf * 16 + frow) * PW + k0 + fk), Mma<T>::load(sR + (pf * 16 + frow) * PW + k0 + fk), acc);
+            const int ox = pf * 16 + (lane & 15);
+            MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                const int j = jf * 16 + 4 * (lane >> 4) + r;
+                if (j < J && ox < OW) hm[(((long)b * J + j) * OH + oy) * OW + ox] = acc[r] + bias[j];
+            }
+        }
+    }
+}
+
+static bool pose_row_width(int w);
+// Backward, row-streaming: workgroup = image, thread = channel (256).  Per output row:
+//   recompute Y, u, R = relu(u) exactly as the forward (registers), keep the ReLU mask as bits,
+//   R -> LDS (T), the row of the heat-map gradient D[j][ox] -> LDS (T, prefetched a row ahead);
+//   dW[j][c] += sum_ox D[j][ox] R[ox][c]          MFMA, K = output columns; 8 accumulator fragments per wave
+//   G[ox][c]  = sum_j  D[j][ox] W[j][c]           MFMA, K = joints (padded to 32) -> LDS in f32
+//   t[sx]    += x-taps of mask * G[ox][c]         VALU, thread = channel: literal tap indices / weights
+//   g0 / g1  += (1-wy) t, wy t                    running token-gradient rows y0, y0+1 in registers; a
+//        source row is written to dtok exactly once (coalesced: 256 threads = 256 channels), when the
+//        output rows move past it.  One writer per element everywhere: deterministic, no atomics.
+template <class T, int WT>
+__global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__ tok, const float* __restrict__ W,
+                                                           const float* __restrict__ dhm, T* __restrict__ dtok,
+                                                           float* __restrict__ slab, int h, int J) {
+    // 512 threads = 256 channels x 2 halves of the output columns: thread (c, half) recomputes / scatters
+    // the columns [half OW/2, (half+1) OW/2) of its channel (literal tap indices need a compile-time
+    // column, hence the two instantiations of the column loops below); both halves keep partial
+    // running rows g0 / g1 and combine them through LDS when a source row is flushed (12 times per image).
+    constexpr int KI = Mma<T>::KI;
+    constexpr bool TR = sizeof(T) == 2;
+    constexpr int PAD = 16 / (int)sizeof(T);
+    constexpr int w = WT, OW = 4 * WT, OH2 = OW / 2, OWM = (OW + 15) & ~15, OWK = (OW + 31) & ~31;
+    constexpr int PR = DIM + PAD;                    // sR rows (channels contiguous)
+    constexpr int PD = OWK + PAD;                    // sD rows (output columns contiguous)
+    constexpr int PWT = 32 + PAD;                    // sWt rows (joints contiguous)
+    constexpr int PG = DIM + 4;                      // sG rows, f32
+    constexpr int NT = 512;
+    constexpr int ND = (32 * OW + NT - 1) / NT;      // heat-map gradient elements per thread per row (joints padded to 32)
+    constexpr int NPF = OWM / 16;
+    static_assert(OH2 <= 64, "ReLU mask bits");
+    MTN_DYN_SMEM(smem);
+    float* sG = reinterpret_cast<float*>(smem);      // [OWM][PG] f32
+    T* sR = reinterpret_cast<T*>(sG + OWM * PG);     // [OWK][PR]  relu(u) (rows >= OW: zero)
+    T* sD = sR + OWK * PR;                           // [32][PD]   D (columns >= OW and rows >= J: zero)
+    T* sWt = sD + 32 * PD;                           // [DIM][PWT] W^T (joints >= J: zero)
+    float* sF = reinterpret_cast<float*>(sR);        // [WT][DIM] f32 flush staging (aliases sR between rows)
+    const int hw = h * w, OH = 4 * h, OHW = OH * OW;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ch = tid & 255, half = tid >> 8;
+    const int b = blockIdx.x;
+    for (int i = tid; i < DIM * 32; i += NT) {
+        const int c = i >> 5, j = i & 31;
+        sWt[c * PWT + j] = from_f<T>(j < J ? W[j * DIM + c] : 0.f);
+    }
+    for (int i = tid; i < (OWK - OW) * DIM; i += NT) sR[(OW + i / DIM) * PR + (i % DIM)] = from_f<T>(0.f);
+    for (int i = tid; i < 32 * PD; i += NT) sD[i] = from_f<T>(0.f);
+    __syncthreads();                                 // the zero fill is ordered before the first row's writes
+    const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + ch;
+    T* const drow = dtok + ((long)b * (hw + 1) + 1) * DIM + ch;
+    const float* dh = dhm + (long)b * J * OHW;
+    const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
+    // this wave's dW fragments: joint half jf = wid >> 2, channel fragments (wid & 3) * 4 .. + 3
+    const int jf = wid >> 2, cf0 = (wid & 3) * 4;
+    f32x4_t acc_dw[4];
+    MTN_UNROLL for (int q = 0; q < 4; ++q) acc_dw[q] = zero4();
+    // heat-map gradient: element i = tid + 512 k of the [32][OW] row tile -> (joint i / OW, column i % OW)
+    float dn[ND], db[ND];
+    MTN_UNROLL for (int k = 0; k < ND; ++k) db[k] = 0.f;
+    auto fetch_d = [&](int oy) {
+        MTN_UNROLL for (int k = 0; k < ND; ++k) {
+            const int i = tid + NT * k, j = i / OW, ox = i - j * OW;
+            dn[k] = (j < J && oy < OH) ? dh[(long)j * OHW + oy * OW + ox] : 0.f;
+        }
+    };
+    fetch_d(0);
+    float t0[WT], t1[WT], g0[WT], g1[WT], ya[WT], tx[WT];
+    MTN_UNROLL for (int sx = 0; sx < WT; ++sx) { g0[sx] = 0.f; g1[sx] = 0.f; }
+    unsigned long long mask = 0ull;                  // bit o: u > 0 at column HALF*OW/2 + o
+    // columns of one half: recompute u, R -> LDS, ReLU mask bits
+    auto xphase = [&](auto hc) {
+        constexpr int HALF = decltype(hc)::value;
+        mask = 0ull;
+        MTN_UNROLL for (int o = 0; o < OH2; ++o) {
+            const int ox = HALF * OH2 + o;
+            const Lerp lx = lerp_coord(ox, WT, OW);  // literals after unrolling
+            const float u = (1.f - lx.w1) * ya[lx.i0] + lx.w1 * ya[lx.i1];
+            mask |= (u > 0.f ? 1ull : 0ull) << o;
+            sR[ox * PR + ch] = from_f<T>(u > 0.f ? u : 0.f);
+        }
+    };
+    // transposed x stencil of one half's columns into tx
+    auto scatter = [&](auto hc) {
+        constexpr int HALF = decltype(hc)::value;
+        MTN_UNROLL for (int o = 0; o < OH2; ++o) {
+            const int ox = HALF * OH2 + o;
+            const Lerp lx = lerp_coord(ox, WT, OW);
+            const float g = ((mask >> o) & 1ull) ? sG[ox * PG + ch] : 0.f;
+            tx[lx.i0] += (1.f - lx.w1) * g;
+            if (lx.i1 != lx.i0) tx[lx.i1] += lx.w1 * g;
+        }
+    };
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    // source row `sy` is complete: the second half hands its partial sums over, the first half writes
+    auto flush = [&](const float* g, int sy) {
+        __syncthreads();                             // everyone is past its reads of sR (the staging aliases it)
+        if (half == 1) { MTN_UNROLL for (int sx = 0; sx < WT; ++sx) sF[sx * DIM + ch] = g[sx]; }
+        __syncthreads();
+        if (half == 0) { MTN_UNROLL for (int sx = 0; sx < WT; ++sx) drow[(long)(sy * w + sx) * DIM] = from_f<T>(g[sx] + sF[sx * DIM + ch]); }
+        __syncthreads();                             // staging consumed before the next row's R lands in sR
+    };
+    int cur_y0 = -1, cur = 0;
+    for (int oy = 0; oy < OH; ++oy) {
+        const Lerp ly = lerp_coord(oy, h, OH);
+        const float wy = ly.w1;
+        if (ly.i0 != cur_y0) {                       // workgroup-uniform: new y interval -> its two token rows
+            const T* s0 = base + (long)ly.i0 * w * DIM;
+            const T* s1 = base + (long)ly.i1 * w * DIM;
+            MTN_UNROLL for (int sx = 0; sx < WT; ++sx) { t0[sx] = to_f<T>(s0[(long)sx * DIM]); t1[sx] = to_f<T>(s1[(long)sx * DIM]); }
+            cur_y0 = ly.i0;
+        }
+        if (ly.i0 != cur) {                          // source row `cur` is complete (before sR is rewritten)
+            flush(g0, cur);
+            MTN_UNROLL for (int sx = 0; sx < WT; ++sx) { g0[sx] = g1[sx]; g1[sx] = 0.f; }
+            cur = ly.i0;
+        }
+        MTN_UNROLL for (int sx = 0; sx < WT; ++sx) ya[sx] = (1.f - wy) * t0[sx] + wy * t1[sx];
+        if (half == 0) xphase(C0{}); else xphase(C1{});
+        MTN_UNROLL for (int k = 0; k < ND; ++k) {    // D row tile from the prefetched registers
+            const int i = tid + NT * k, j = i / OW, ox = i - j * OW;
+            if (i < 32 * OW) sD[j * PD + ox] = from_f<T>(dn[k]);
+            db[k] += dn[k];
+        }
+        fetch_d(oy + 1);                             // the next row's gradient travels under this row's work
+        __syncthreads();                             // sR, sD complete
+        // dW[j][c] += D[j][ox] R[ox][c]
+        for (int k0 = 0; k0 < OWK; k0 += KI) {
+            const typename Mma<T>::Frag fa = Mma<T>::load(sD + (jf * 16 + frow) * PD + k0 + fk);
+            typename Mma<T>::Frag fr[4];
+            MTN_UNROLL for (int q = 0; q < 4; ++q) fr[q] = ColFrag<T, TR>::load(sR + k0 * PR + (cf0 + q) * 16, PR, lane);
+            MTN_UNROLL for (int q = 0; q < 4; ++q) acc_dw[q] = Mma<T>::mma(fa, fr[q], acc_dw[q]);
+        }
+        // G[ox][c] = D^T W : the W^T fragment is the row operand -> a lane's quad is 4 consecutive channels.
+        // Wave w owns channel fragments 2w, 2w+1 for every pixel fragment; all operand fragments of a K
+        // step are read before its MFMAs issue.
+        {
+            f32x4_t g[NPF][2];
+            MTN_UNROLL for (int pf = 0; pf < NPF; ++pf) { g[pf][0] = zero4(); g[pf][1] = zero4(); }
+            MTN_UNROLL for (int k0 = 0; k0 < 32; k0 += KI) {
+                typename Mma<T>::Frag fw[2], fd[NPF];
+                MTN_UNROLL for (int q = 0; q < 2; ++q) fw[q] = Mma<T>::load(sWt + ((wid * 2 + q) * 16 + frow) * PWT + k0 + fk);
+                MTN_UNROLL for (int pf = 0; pf < NPF; ++pf) fd[pf] = ColFrag<T, TR>::load(sD + k0 * PD + pf * 16, PD, lane);
+                MTN_UNROLL for (int pf = 0; pf < NPF; ++pf)
+                    MTN_UNROLL for (int q = 0; q < 2; ++q) g[pf][q] = Mma<T>::mma(fw[q], fd[pf], g[pf][q]);
+            }
+            MTN_UNROLL for (int pf = 0; pf < NPF; ++pf)
+                MTN_UNROLL for (int q = 0; q < 2; ++q)
+                    store4<float>(sG + (pf * 16 + (lane & 15)) * PG + (wid * 2 + q) * 16 + 4 * (lane >> 4), g[pf][q]);
+        }
+        __syncthreads();                             // sG complete; everyone is done with sR / sD
+        MTN_UNROLL for (int sx = 0; sx < WT; ++sx) tx[sx] = 0.f;
+        if (half == 0) scatter(C0{}); else scatter(C1{});
+        MTN_UNROLL for (int sx = 0; sx < WT; ++sx) {
+            g0[sx] += (1.f - wy) * tx[sx];
+            if (ly.i1 != ly.i0) g1[sx] += wy * tx[sx];
+        }
+    }
+    flush(g0, cur);                                  // the last one or two source rows
+    if (cur + 1 < h) flush(g1, cur + 1);
+    float* row = slab + (long)b * J * (DIM + 1);
+    MTN_UNROLL for (int q = 0; q < 4; ++q)
+        MTN_UNROLL for (int r = 0; r < 4; ++r) {     // accumulator: row = joint, column = channel
+            const int j = jf * 16 + 4 * (lane >> 4) + r;
+            if (j < J) row[j * DIM + (cf0 + q) * 16 + (lane & 15)] = acc_dw[q][r];
+        }
+    // dbias[j] = sum of this image's gradient row j: element i always belongs to joint i / OW
+    __syncthreads();
+    float* red = sG;                                 // [32 * OW]
+    MTN_UNROLL for (int k = 0; k < ND; ++k) { const int i = tid + NT * k; if (i < 32 * OW) red[i] = db[k]; }
+    __syncthreads();
+    if (tid < J) {
+        float v = 0.f;
+        for (int ox = 0; ox < OW; ++ox) v += red[tid * OW + ox];
+        row[J * DIM + tid] = v;
+    }
+}
+
+template <class T>
+static size_t pose_bwd_row_lds(int w) {
+    const int OW = 4 * w, OWM = (OW + 15) & ~15, OWK = (OW + 31) & ~31, pad = 16 / (int)sizeof(T);
+    return (size_t)OWM * (DIM + 4) * 4 + ((size_t)OWK * (DIM + pad) + 32 * (size_t)(OWK + pad) + (size_t)DIM * (32 + pad)) * sizeof(T);
+}
+template <class T, int WT>
+static void pose_bwd_row_launch(int B, size_t lds, hipStream_t stream, const void* tok, const float* W, const float* dhm, void* dtok,
+                                float* slab, int h, int J) {
+#ifndef MTN_EMU
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &pose_bwd_row_kernel<T, WT>, 160 * 1024);
+#endif
+    MTN_LAUNCH((pose_bwd_row_kernel<T, WT>), dim3(B), dim3(512), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, J);
+}
+template <class T>
+static void pose_bwd_row_dispatch(int w, int B, size_t lds, hipStream_t stream, const void* tok, const float* W, const float* dhm,
+                                  void* dtok, float* slab, int h, int J) {
+    if (w == 6) pose_bwd_row_launch<T, 6>(B, lds, stream, tok, W, dhm, dtok, slab, h, J);
+    else if (w == 12) pose_bwd_row_launch<T, 12>(B, lds, stream, tok, W, dhm, dtok, slab, h, J);
+    else pose_bwd_row_launch<T, 24>(B, lds, stream, tok, W, dhm, dtok, slab, h, J);
+}
+
+template <class T>
+static size_t pose_fwd_row_lds(int w) {
+    const int OW = 4 * w, OWM = (OW + 15) & ~15;
+    return (size_t)(32 + OWM) * (DIM * sizeof(T) + 16);
+}
+// instantiated map widths: 12 (192^2 images), 24 (384^2), 6 (96^2; also the CPU kernel-logic tests)
+static bool pose_row_width(int w) { return w == 6 || w == 12 || w == 24; }
+template <class T, int WT>
+static void pose_fwd_row_launch(dim3 grid, size_t lds, hipStream_t stream, const void* tok, const float* W, const float* bias,
+                                float* hm, int h, int J, int rpb) {
+#ifndef MTN_EMU
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &pose_fwd_row_kernel<T, WT>, 160 * 1024);
+#endif
+    MTN_LAUNCH((pose_fwd_row_kernel<T, WT>), grid, dim3(256), lds, stream, (const T*)tok, W, bias, hm, h, J, rpb);
+}
+template <class T>
+static void pose_fwd_row_dispatch(int w, dim3 grid, size_t lds, hipStream_t stream, const void* tok, const float* W,
+                                  const float* bias, float* hm, int h, int J, int rpb) {
+    if (w == 6) pose_fwd_row_launch<T, 6>(grid, lds, stream, tok, W, bias, hm, h, J, rpb);
+    else if (w == 12) pose_fwd_row_launch<T, 12>(grid, lds, stream, tok, W, bias, hm, h, J, rpb);
+    else pose_fwd_row_launch<T, 24>(grid, lds, stream, tok, W, bias, hm, h, J, rpb);
+}
+
 // ---- loss ------------------------------------------------------------------------------------------
 // dhm = w^2 (p - t) / n ; partial[block] = sum 0.5 (w (p - t))^2 / n,  n = B*J*HW
 __global__ __launch_bounds__(256) void jmse_kernel(const float* __restrict__ hm, const float* __restrict__ tgt,
@@ -705,6 +1004,8 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
 }  // namespace
 
 static int g_pose_mma = 1;      // debug key 2: 1 selects the VALU kernels
+static int g_pose_row = 1;      // debug key 14: 0 selects the round-1 chunk/tile kernels
+void mtn_pose_set_row(int on) { g_pose_row = on; }
 static int pose_bwd_rb(int h, int w);
 
 template <class T>
@@ -718,6 +1019,18 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
                      hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_fwd: bad sizes (J=%d, max %d)", J, MAXJ);
     const int OH = 4 * h, OW = 4 * w;
+    {
+        const size_t lds = dtype == MTN_BF16 ? pose_fwd_row_lds<bf16_t>(w) : pose_fwd_row_lds<float>(w);
+        if (g_pose_row && pose_row_width(w) && lds <= 160 * 1024) {   // row-streaming kernel: all 256 channels per workgroup
+            int bands = mtn_cdiv(768, B);                 // >= 768 workgroups (three per CU at B = 256: 42 KB of LDS each)
+            if (bands > OH) bands = OH;
+            const int rpb = mtn_cdiv(OH, bands);
+            const dim3 grid(mtn_cdiv(OH, rpb), B);
+            if (dtype == MTN_BF16) pose_fwd_row_dispatch<bf16_t>(w, grid, lds, stream, tok, W, bias, hm, h, J, rpb);
+            else pose_fwd_row_dispatch<float>(w, grid, lds, stream, tok, W, bias, hm, h, J, rpb);
+            return mtn_check_launch("pose_fwd_row");
+        }
+    }
     if (g_pose_mma && 4 * w <= PB_MAXPX && w <= 32) {    // MFMA path: rows of the map as matrix products
         const int rb = pose_bwd_rb(h, w);
         const dim3 grid(mtn_cdiv(mtn_cdiv(OH, rb), PF_TILES), B);
@@ -796,7 +1109,12 @@ int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dt
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
     int rc;
     const size_t mma_lds = !g_pose_mma ? 0 : (dtype == MTN_BF16 ? pose_bwd_mma_lds<bf16_t>(h, w) : pose_bwd_mma_lds<float>(h, w));
-    if (mma_lds) {
+    const size_t row_lds = dtype == MTN_BF16 ? pose_bwd_row_lds<bf16_t>(w) : pose_bwd_row_lds<float>(w);
+    if (g_pose_row && pose_row_width(w) && row_lds <= 160 * 1024 && J <= 32) {
+        if (dtype == MTN_BF16) pose_bwd_row_dispatch<bf16_t>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
+        else pose_bwd_row_dispatch<float>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
+        rc = mtn_check_launch("pose_bwd_row");
+    } else if (mma_lds) {
         if (dtype == MTN_BF16) rc = pose_bwd_mma_launch<bf16_t>(tok, W, dhm, dtok, slab, B, h, w, J, mma_lds, stream);
         else rc = pose_bwd_mma_launch<float>(tok, W, dhm, dtok, slab, B, h, w, J, mma_lds, stream);
     } else if (J == 21) {      // hagrid.yaml: num_joints = 21 -> fully unrolled joint loops

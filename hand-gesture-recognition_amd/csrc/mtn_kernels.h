@@ -129,6 +129,7 @@ int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int
 int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                     float* scale_shift, int C, hipStream_t stream);
 void mtn_pose_set_dbg(int v);
+void mtn_pose_set_row(int on);
 void mtn_igemm_set_stages(int n);
 
 int mtn_hm_argmax_run(const float* hm, float* preds, float* maxvals, int maps, int H, int W, hipStream_t stream);

@@ -140,7 +140,8 @@ def test_cls_head(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17)])
+@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17),
+                                 (2, 6, 6, 21), (1, 3, 6, 17), (1, 24, 24, 21), (3, 5, 12, 21)])   # widths 6 / 12 / 24: the row-streaming kernels
 def test_pose_head(be, dtype, cfg):
     B, h, w, J = cfg
     if be.name == "emu" and h * w > 50:
