@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0              # HBM3E spec (same guide: ~6.3 TB/s achievable)
 TRAIN_GFLOP_PER_IMG = 13.09        # fwd + dgrad + wgrad @192^2
 
 
@@ -66,16 +67,16 @@ def igemm_roofline(step, batch):
 
     def g_fwd(x, w, y, stats, k, s, stats_tiles=None):
         Cin, Cout, M = x.shape[-1], y.shape[-1], y.numel() // y.shape[-1]
-        return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y)
+        return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y), k
 
     def g_dgrad(dy, wt, dx, res, k, s):
         Cout, Cin, Mout = dy.shape[-1], dx.shape[-1], dy.numel() // dy.shape[-1]
-        return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res)
+        return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res), k
 
     def g_lin(x, w, out, bias=None, act=0, aux_out=None, res=None):
         K, N = x.shape[-1], out.shape[-1]
         M = x.numel() // K
-        return 2.0 * M * N * K, nbytes(x, w, out, aux_out, res)
+        return 2.0 * M * N * K, nbytes(x, w, out, aux_out, res), 1
 
     saved = (ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd)
     ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = (wrap("conv_fwd", saved[0], g_fwd), wrap("conv_dgrad", saved[1], g_dgrad),
@@ -87,8 +88,24 @@ def igemm_roofline(step, batch):
         ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = saved
     flops = sum(r[1][0] for r in rec)
     abytes = sum(r[1][1] for r in rec)
-    secs = sum(r[2].elapsed_time(r[3]) for r in rec) * 1e-3
+    times = [r[2].elapsed_time(r[3]) * 1e-3 for r in rec]
+    secs = sum(times)
     achieved = flops / secs / 1e12
+    # the template's two regimes, reported separately as well: 3x3 convolutions (forward and data gradient;
+    # MFMA-bound: 288..1152 flop/B) and 1x1 convolutions / Linears (HBM-bound: 64..256 flop/B)
+    fam = {}
+    for r, t in zip(rec, times):
+        k = "conv3x3" if r[1][2] == 3 else "pointwise"
+        f = fam.setdefault(k, [0.0, 0.0, 0.0, 0])
+        f[0] += r[1][0]; f[1] += r[1][1]; f[2] += t; f[3] += 1
+    families = {
+        "conv3x3": {"bound": "mfma", "achieved": round(fam["conv3x3"][0] / fam["conv3x3"][2] / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fam["conv3x3"][0] / fam["conv3x3"][2] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "launches_per_step": fam["conv3x3"][3], "share_of_step_ms": round(fam["conv3x3"][2] * 1e3, 3)},
+        "pointwise": {"bound": "hbm", "achieved": round(fam["pointwise"][1] / fam["pointwise"][2] / 1e9, 1), "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": round(fam["pointwise"][1] / fam["pointwise"][2] / 1e9 / HBM_PEAK_GBS, 4),
+                      "launches_per_step": fam["pointwise"][3], "share_of_step_ms": round(fam["pointwise"][2] * 1e3, 3)},
+    }
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes),
     # averaged over all instances of the template
@@ -98,19 +115,18 @@ def igemm_roofline(step, batch):
     # newest collection: highest round, then highest version (r02_..._v3 > r02_..._v2 > r01_..._v10)
     cands.sort(key=lambda n: [int(x) for x in re.findall(r"\d+", n)], reverse=True)
     for name in cands:
-        if True:
-            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-            tot = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
-            n = sum(v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
-            if n:
-                traffic, src = round(tot / n), "profiles/" + name
-            break
+        pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        tot = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
+        n = sum(v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
+        if n:
+            traffic, src = round(tot / n), "profiles/" + name
+        break
     return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,...> (all instances: conv fwd + conv dgrad + ViT linears, one launch per call)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
             "flops_per_launch": round(flops / len(rec)), "algorithmic_bytes_per_launch": round(abytes / len(rec)),
-            "share_of_step_ms": round(secs * 1e3, 3)}
+            "share_of_step_ms": round(secs * 1e3, 3), "families": families}
 
 
 def cpu_baseline(size):
