@@ -235,9 +235,131 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     // (One dynamic array with a runtime stage offset: hipcc then cannot tell the stage being filled from
     // the stage being read and waits vmcnt(0) before the first fragment read after every DMA issue, i.e.
     // a workgroup does not overlap its own DMA with its own MFMAs -- the 2..4 co-resident workgroups
-    // overlap each other instead.  Two distinct __shared__ stages remove that wait (wgrad3_kernel below
-    // does it), but here it measured SLOWER on 10 of 13 layers (conv2 +24 %, down1/2 +12 %, cv4 +17 %):
-    // the in-flight DMA then contends with the fragment reads of the same workgroup.)
+    // overlap each other instead.  Two distinct __shared__ stages + a step loop unrolled by two remove
+    // that wait (wgrad3_kernel below does it), but here it measured SLOWER on 10 of 13 layers (conv2
+    // +24 %, down1/2 +12 %, cv4 +17 %), and even the unrolled loop alone costs the 128x64 tile 60
+    // registers and a resident workgroup.)
+    MTN_DYN_SMEM(smem);
+    T* const sY = reinterpret_cast<T*>(smem);          // [2][BMR][BN]
+    T* const sX = sY + 2 * BMR * BN;                   // [2][BMR][BC]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+
+    const int tiles_n = p.N / BN;
+    const int tiles = tiles_n * (p.K / BC);
+    int tile, split;
+    {
+        const int L = blockIdx.x;
+        if (p.splits % 8 == 0 && tiles <= 24) {
+            const int xcd = L & 7, j = L >> 3;
+            split = (j / tiles) * 8 + xcd;
+            tile = j % tiles;
+        } else {
+            // many tiles per split: give each XCD group (id % 8) a contiguous range of the
+            // (split, tile) order, so the tiles of one split -- which all stream the same rows of
+            // dY and X -- share one L2 instead of spreading over all eight
+            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+            const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+            split = lin / tiles;
+            tile = lin % tiles;
+        }
+    }
+    const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
+    const int n0 = tile_n * BN;
+    const int kcol0 = tile_k * BC;
+    const int tap = kcol0 / p.Cin, c0 = kcol0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const bool pointwise = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
+    const long m_begin = (long)split * p.rows_per_split;
+    long m_end = m_begin + p.rows_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int steps = (int)((m_end - m_begin + BMR - 1) / BMR);
+
+    const BufDesc bufY = make_buf(p.dY, p.y_bytes), bufX = make_buf(p.X, p.x_bytes);
+    // this lane's row / source chunk in each of its DMA instructions
+    int yrow[IY], ychunk[IY];
+    MTN_UNROLL for (int i = 0; i < IY; ++i) {
+        yrow[i] = (wid * IY + i) * RPBY + lane / CPRY;
+        ychunk[i] = Swz<T, BN>::fetch_chunk(yrow[i], lane % CPRY);
+    }
+    int xrow[IX], xchunk[IX];
+    PixelPos xpos[IX];
+    MTN_UNROLL for (int i = 0; i < IX; ++i) {
+        xrow[i] = (wid * IX + i) * RPBX + lane / CPRX;
+        xchunk[i] = Swz<T, BC>::fetch_chunk(xrow[i], lane % CPRX);
+        xpos[i] = pointwise ? PixelPos{0, 0, 0} : pixel_of(m_begin + xrow[i], p);
+    }
+    auto dma_tiles = [&](int st, int stage) {
+        const long mb = m_begin + (long)st * BMR;
+        char* y = reinterpret_cast<char*>(sY + stage * BMR * BN);
+        char* x = reinterpret_cast<char*>(sX + stage * BMR * BC);
+        MTN_UNROLL for (int i = 0; i < IY; ++i) {
+            const long m = mb + yrow[i];
+            const unsigned off = (unsigned)(m * p.lddy + n0 + ychunk[i] * VEC) * (unsigned)sizeof(T);
+            buf_glds16(bufY, m < m_end ? off : 0xFFFFFFF0u, y + (wid * IY + i) * 1024);
+        }
+        MTN_UNROLL for (int i = 0; i < IX; ++i) {
+            const long m = mb + xrow[i];
+            if (pointwise) {                                 // 1x1 taps at stride 1: input pixel m itself
+                const unsigned off = (unsigned)(m * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
+                buf_glds16(bufX, m < m_end ? off : 0xFFFFFFF0u, x + (wid * IX + i) * 1024);
+                continue;
+            }
+            const int iy = xpos[i].oy * p.stride - p.pad + kh, ix = xpos[i].ox * p.stride - p.pad + kw;
+            const bool ok = (m < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned off = (unsigned)(((xpos[i].b * p.H + iy) * p.W + ix) * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
+            buf_glds16(bufX, ok ? off : 0xFFFFFFF0u, x + (wid * IX + i) * 1024);
+            pixel_advance(xpos[i], BMR, p);
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = zero4();
+
+    if (steps > 0) dma_tiles(0, 0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < steps) dma_tiles(st + 1, cur ^ 1);
+        const T* y = sY + cur * BMR * BN;
+        const T* x = sX + cur * BMR * BC;
+        MTN_UNROLL for (int ks = 0; ks < BMR / KI; ++ks) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFragS<T, BN>::load(y, ks * KI, wm * WM + i * 16, lane);
+            MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = ColFragS<T, BC>::load(x, ks * KI, wn * WN + j * 16, lane);
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = p.partial + (long)split * p.N * p.K;
+    MTN_UNROLL for (int i = 0; i < FM; ++i)
+        MTN_UNROLL for (int j = 0; j < FN; ++j)
+            {   // the X fragment is the MFMA's row operand: a lane's quad is 4 consecutive k of one n
+                const int n = n0 + wm * WM + i * 16 + (lane & 15);
+                const int k = kcol0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                store4<float>(out + (long)n * p.K + k, acc[i][j]);
+            }
+}
+
+// The same kernel with its step loop unrolled by two (each copy names its read / fill stage by a
+// pointer fixed outside the loop): measured 5 % faster on the 8-wave 128x128 tile, and slower on the
+// 128x64 tile (the second copy of the loader state costs it 50 registers and a resident workgroup),
+// so only the former uses it.
+template <class T, int BN, int BC, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BMR = 128 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
+    constexpr int CPRY = BN / VEC, CPRX = BC / VEC;                 // 16-byte slots per row
+    constexpr int RPBY = 64 / CPRY, RPBX = 64 / CPRX;               // rows per 1 KiB DMA block
+    constexpr int IY = BMR / RPBY / NW, IX = BMR / RPBX / NW;       // DMA instructions per wave per step
+    constexpr int WM = BN / WGM, WN = BC / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    static_assert(BMR % (RPBY * NW) == 0 && BMR % (RPBX * NW) == 0, "DMA mapping");
+
     MTN_DYN_SMEM(smem);
     T* const sStage0 = reinterpret_cast<T*>(smem);               // [BMR][BN] dY then [BMR][BC] X
     T* const sStage1 = sStage0 + BMR * (BN + BC);
@@ -584,6 +706,14 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
     mtn_set_max_lds(attr, &wgrad_dma_kernel<T, BN, BC, WGM, WGN>, lds);
 #endif
     const int tiles = (p.N / BN) * (p.K / BC);
+    if (BN == 128 && BC == 128 && WGM * WGN == 8) {
+#ifndef MTN_EMU
+        static MtnLdsAttr attr2;
+        mtn_set_max_lds(attr2, &wgrad_dma2_kernel<T, BN, BC, WGM, WGN>, lds);
+#endif
+        MTN_LAUNCH((wgrad_dma2_kernel<T, BN, BC, WGM, WGN>), dim3(tiles * p.splits), dim3(NT), lds, stream, p);
+        return mtn_check_launch("wgrad_dma2");
+    }
     MTN_LAUNCH((wgrad_dma_kernel<T, BN, BC, WGM, WGN>), dim3(tiles * p.splits), dim3(NT), lds, stream, p);
     return mtn_check_launch("wgrad_dma");
 }
