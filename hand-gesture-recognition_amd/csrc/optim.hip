@@ -54,9 +54,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
     // inner = the destination's fastest axis (I for [o][tap][i], O for [i][tap][o]); one runtime division
     // per element (by inner), the tap split is by a literal 1 or 9 (the model's kernels), generic otherwise
     const int inner = mode == 0 ? I : O;
-    const unsigned magic = inner > 1 ? (unsigned)(0x100000000ull / (unsigned)inner) + 1u : 0u;     // exact for idx * inner < 2^32
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        const int q = inner > 1 ? (int)__umulhi((unsigned)idx, magic) : idx;     // idx / inner
+        const int q = (int)((unsigned)idx / (unsigned)inner);
         const int f = idx - q * inner;                                           // idx % inner
         int outer, tap;
         if (taps == 1) { outer = q; tap = 0; }
@@ -82,7 +81,6 @@ int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* s
 
 int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream) {
     MTN_REQUIRE(ntensors > 0 && max_elems > 0, "pack: bad sizes");
-    MTN_REQUIRE((long)max_elems * 2048 < (1L << 32), "pack: tensor too large for the multiply-high index split (channels <= 2048)");
     int bx = (max_elems + 255) / 256;
     if (bx > 256) bx = 256;
     if (dtype == MTN_BF16) MTN_LAUNCH(pack_kernel<bf16_t>, dim3(bx, ntensors), dim3(256), 0, stream, src, (bf16_t*)dst, desc);
