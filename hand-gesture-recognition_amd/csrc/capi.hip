@@ -298,6 +298,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 12) { mtn_conv1_set_bwd_px(value); return MTN_OK; }
     if (key == 13) { mtn_wgrad_set_win(value); return MTN_OK; }
     if (key == 14) { mtn_pose_set_row(value); return MTN_OK; }
+    if (key == 15) { mtn_dgrad2_set(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

@@ -1,0 +1,232 @@
+// dgrad2.hip -- data gradient of the 3x3 stride-2 pad-1 convolutions (conv2, down1, down2, down3:
+// model/gelan.py:156-164; autograd of nn.Conv2d), all four output parities from one workgroup.
+//
+//   dx[b][2a+qy][2c+qx][n] = sum over the taps (kh, kw) with kh = 1 (qy = 0) or kh in {0, 2} (qy = 1),
+//                            likewise kw / qx, of  dy[b][a + (kh == 0)][c + (kw == 0)][:] . W[:][n][kh][kw]
+//
+// A row of the tile is one dy pixel (b, a, c) = one 2x2 block of dx.  The nine taps of that block read
+// only FOUR dy pixels -- (a, c), (a, c+1), (a+1, c), (a+1, c+1) -- which in the flattened (b, a, c)
+// order are rows m, m+1, m+Wd, m+Wd+1: the BM rows of a tile need the CONTIGUOUS dy rows
+// [m0, m0 + BM + Wd + 1).  That window is DMA-ed into LDS once per 128-byte x 2 channel slab and every
+// tap reads its operand fragments from it at a row offset (a zero row where c+1 / a+1 leave the image);
+// each tap accumulates into the accumulator set of the parity class it produces, so the dy operand
+// crosses L2 -> LDS once instead of once per tap and class (igemm.hip's parity-major rows: 2.25 taps
+// x 4 classes, each class its own short-K workgroup with its own prologue, epilogue and scattered
+// 128-byte stores).  Only the 64 x 128-byte weight tiles stream per tap.  The epilogue writes whole
+// 2x2 blocks: both x parities of an output row are adjacent in memory.
+//
+// 8 waves (4 row groups x 2 column groups; 32 x 32 per wave and class), 2 workgroups per CU.
+#include <type_traits>
+#include "mtn_types.h"
+#include "mtn_kernels.h"
+
+namespace {
+
+#ifdef MTN_EMU
+#define MTN_D2_WAVES(n)
+#else
+#define MTN_D2_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
+constexpr int D2_BM = 128, D2_BN = 64, D2_NT = 512, D2_CS = 2;
+
+template <class T>
+__global__ __launch_bounds__(D2_NT) MTN_D2_WAVES(sizeof(T) == 2 ? 4 : 2)
+void dgrad2_kernel(IgemmArgs p) {
+    constexpr int BM = D2_BM, BN = D2_BN, NT = D2_NT, CS = D2_CS;
+    constexpr int BK = 128 / (int)sizeof(T);            // elements per 128-byte LDS row
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI, KS = BK / KI, NS = CS * KS;
+    constexpr int FM = 2, FN = 2;
+    constexpr int CPR = 2 * BN / VEC;                   // 16-byte chunks of one staged row (both x parities)
+    constexpr int CP = 2 * BN + 16 / (int)sizeof(T);    // its pitch in elements
+    static_assert(NT % CPR == 0, "store mapping");
+
+    MTN_DYN_SMEM(smem);
+    const int Wd = p.W, Hd = p.H, Cd = p.Cin;
+    const int Md = p.B * Hd * Wd;
+    const int WR8 = (BM + Wd + 1 + 7) & ~7;
+    T* const sW = reinterpret_cast<T*>(smem);           // [2 stages][CS][BN][BK]
+    T* const sWin = sW + 2 * CS * BN * BK;              // [CS][WR8][BK]
+    const int zero_off = CS * WR8 * BK;                 // (relative to sWin) one zero row
+    T* const sC = reinterpret_cast<T*>(smem);           // [BM][CP] per output-row parity (after the K loop)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 3, wn = wid >> 2;
+    const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
+
+    // XCD-aware tile order as in igemm.hip: the N/BN column tiles of one window share an XCD's L2
+    const int tiles_n = p.N / BN, nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    auto decode = [&](int m, int& b, int& a, int& c) {
+        const unsigned yt = Wd == 1 ? (unsigned)m : __umulhi((unsigned)m, p.magic_w);     // m / Wd
+        c = m - (int)yt * Wd;
+        b = Hd == 1 ? (int)yt : (int)__umulhi(yt, p.magic_h);                             // yt / Hd
+        a = (int)yt - b * Hd;
+    };
+    // per fragment row of this lane: may the row read its right / lower neighbour?
+    bool f_vx[FM], f_vy[FM];
+    MTN_UNROLL for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + frow;
+        int b, a, c;
+        decode(m < Md ? m : 0, b, a, c);
+        f_vx[i] = m < Md && c + 1 < Wd;
+        f_vy[i] = m < Md && a + 1 < Hd;
+    }
+    if (tid < 128 / 4) reinterpret_cast<unsigned*>(sWin + zero_off)[tid] = 0u;
+
+    const BufDesc bufA = make_buf(p.A, p.a_bytes), bufW = make_buf(p.Wp, p.w_bytes);
+    const int dchunk = ((lane & 7) ^ (lane >> 3)) * VEC;          // source chunk of this lane (XOR swizzle by row & 7)
+    auto dma_window = [&](int slab) {
+        const int ppc = WR8 >> 3;                                  // 1 KiB pieces per 128-byte channel slab
+        for (int q = wid; q < CS * ppc; q += NT / 64) {
+            const int cs = q / ppc, pr = q - cs * ppc;
+            const int g = m0 + pr * 8 + (lane >> 3);
+            const unsigned e = (unsigned)(g * p.lda + (slab * CS + cs) * BK + dchunk) * (unsigned)sizeof(T);
+            buf_glds16(bufA, g < Md ? e : 0xFFFFFFF0u, reinterpret_cast<char*>(sWin + (cs * WR8 + pr * 8) * BK));
+        }
+    };
+    auto dma_w = [&](int slab, int tap, int stage) {
+        MTN_UNROLL for (int q = wid; q < CS * (BN / 8); q += NT / 64) {
+            const int cs = q / (BN / 8), pr = q - cs * (BN / 8);
+            const int n = n0 + pr * 8 + (lane >> 3);
+            const unsigned e = (unsigned)(n * p.K + tap * Cd + (slab * CS + cs) * BK + dchunk) * (unsigned)sizeof(T);
+            buf_glds16(bufW, e, reinterpret_cast<char*>(sW + ((stage * CS + cs) * BN + pr * 8) * BK));
+        }
+    };
+
+    f32x4_t acc[4][FM][FN];
+    MTN_UNROLL for (int q = 0; q < 4; ++q)
+        MTN_UNROLL for (int i = 0; i < FM; ++i)
+            MTN_UNROLL for (int j = 0; j < FN; ++j) acc[q][i][j] = zero4();
+
+    // one tap: class (kh != 1, kw != 1) += W[kh][kw] x window rows shifted by (kh == 0, kw == 0)
+    auto compute = [&](auto TAP, int stage) {
+        constexpr int t = decltype(TAP)::value, kh = t / 3, kw = t % 3;
+        constexpr int cls = (kh != 1 ? 2 : 0) + (kw != 1 ? 1 : 0);
+        constexpr bool da = kh == 0, dc = kw == 0;
+        const T* wb = sW + (stage * CS * BN + wn * 32 + frow) * BK;
+        const int swb = frow & 7;
+        int aoff[FM], acs[FM], asw[FM];
+        MTN_UNROLL for (int i = 0; i < FM; ++i) {
+            const int j = wm * 32 + i * 16 + frow + (da ? Wd : 0) + (dc ? 1 : 0);
+            const bool ok = (!da || f_vy[i]) && (!dc || f_vx[i]);
+            aoff[i] = ok ? j * BK : zero_off;
+            acs[i] = ok ? WR8 * BK : 0;
+            asw[i] = j & 7;
+        }
+        typename Mma<T>::Frag fa[2][FM], fb[2][FN];
+        auto load = [&](int s, int buf) {
+            const int cs = s / KS, e = (s % KS) * KI + fk;
+            MTN_UNROLL for (int j = 0; j < FN; ++j)
+                fb[buf][j] = Mma<T>::load(wb + (cs * BN + j * 16) * BK + (((e / VEC) ^ swb) * VEC) + (e % VEC));
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                fa[buf][i] = Mma<T>::load(sWin + aoff[i] + cs * acs[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC));
+        };
+        load(0, 0);
+        MTN_UNROLL for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) load(s + 1, (s + 1) & 1);
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j)
+                    acc[cls][i][j] = Mma<T>::mma(fb[s & 1][j], fa[s & 1][i], acc[cls][i][j]);
+        }
+    };
+    // tap t of a slab: the next tap's weight tile streams in while this one is multiplied
+    auto tap_step = [&](auto TAP, int slab) {
+        constexpr int t = decltype(TAP)::value;
+        if (t + 1 < 9) dma_w(slab, t + 1, (t + 1) & 1);
+        compute(TAP, t & 1);
+        __syncthreads();
+    };
+
+    const int slabs = Cd / (CS * BK);
+    for (int slab = 0; slab < slabs; ++slab) {
+        if (slab) __syncthreads();
+        dma_window(slab);
+        dma_w(slab, 0, 0);
+        __syncthreads();
+        tap_step(std::integral_constant<int, 0>{}, slab);
+        tap_step(std::integral_constant<int, 1>{}, slab);
+        tap_step(std::integral_constant<int, 2>{}, slab);
+        tap_step(std::integral_constant<int, 3>{}, slab);
+        tap_step(std::integral_constant<int, 4>{}, slab);
+        tap_step(std::integral_constant<int, 5>{}, slab);
+        tap_step(std::integral_constant<int, 6>{}, slab);
+        tap_step(std::integral_constant<int, 7>{}, slab);
+        tap_step(std::integral_constant<int, 8>{}, slab);
+    }
+
+    // ---- epilogue: per output-row parity qy, both x parities staged as [row][qx][n] -> 16-byte stores ----
+    T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
+    const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
+    const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
+    const int qx = ccol / BN, col = ccol - qx * BN;
+    MTN_UNROLL for (int qy = 0; qy < 2; ++qy) {
+        if (qy) __syncthreads();
+        MTN_UNROLL for (int x = 0; x < 2; ++x)
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j)
+                    store4<T>(sC + (wm * 32 + i * 16 + frow) * CP + x * BN + wn * 32 + j * 16 + 4 * (lane >> 4), acc[qy * 2 + x][i][j]);
+        __syncthreads();
+        for (int row = trow; row < BM; row += NT / CPR) {
+            const int m = m0 + row;
+            if (m >= Md) break;
+            int b, a, c;
+            decode(m, b, a, c);
+            const long o = (long)(b * p.OH + 2 * a + qy) * p.OW + 2 * c + qx;
+            chunk16 v = *reinterpret_cast<const chunk16*>(sC + row * CP + ccol);
+            if (gR) {
+                float f[VEC], r[VEC];
+                unpack<T>(v, f);
+                unpack<T>(*reinterpret_cast<const chunk16*>(gR + o * p.ldr + n0 + col), r);
+                MTN_UNROLL for (int e = 0; e < VEC; ++e) f[e] += r[e];
+                v = pack<T>(f);
+            }
+            *reinterpret_cast<chunk16*>(gO + o * p.ldc + n0 + col) = v;
+        }
+    }
+}
+
+size_t dgrad2_lds(const IgemmArgs& p, int esz) {
+    const size_t wr8 = (size_t)((D2_BM + p.W + 1 + 7) & ~7);
+    const size_t loop = (2 * (size_t)D2_BN + wr8) * D2_CS * 128 + 128;
+    const size_t epi = (size_t)D2_BM * (2 * D2_BN * esz + 16);
+    return loop > epi ? loop : epi;
+}
+
+int g_dgrad2 = 1;     // debug key 15
+
+template <class T>
+int launch_dgrad2(const IgemmArgs& p, hipStream_t stream) {
+    const size_t lds = dgrad2_lds(p, (int)sizeof(T));
+#ifndef MTN_EMU
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &dgrad2_kernel<T>, 80 * 1024);
+#endif
+    const long tiles = (long)mtn_cdiv((long)p.B * p.H * p.W, D2_BM) * (p.N / D2_BN);
+    MTN_LAUNCH(dgrad2_kernel<T>, dim3((unsigned)tiles), dim3(D2_NT), lds, stream, p);
+    return mtn_check_launch("dgrad2");
+}
+
+}  // namespace
+
+void mtn_dgrad2_set(int on) { g_dgrad2 = on ? 1 : 0; }
+
+// the fused form serves 3x3 stride-2 pad-1 data gradients whose window still lets two workgroups share a CU
+bool mtn_dgrad2_ok(const IgemmArgs& p, int dtype) {
+    const int esz = dtype == MTN_BF16 ? 2 : 4, bk = 128 / esz;
+    return g_dgrad2 && p.pm && p.KH == 3 && p.KW == 3 && p.div == 2 && p.mul == 1 && p.sgn == -1 && p.off == 1 &&
+           p.OH == 2 * p.H && p.OW == 2 * p.W && p.Cin % (D2_CS * bk) == 0 && p.N % D2_BN == 0 && !p.bias && !p.stats &&
+           p.act == MTN_ACT_NONE && !p.aux_out && dgrad2_lds(p, esz) <= 80 * 1024;
+}
+
+int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
+    return dtype == MTN_BF16 ? launch_dgrad2<bf16_t>(p, stream) : launch_dgrad2<float>(p, stream);
+}

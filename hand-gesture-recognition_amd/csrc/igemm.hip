@@ -766,5 +766,6 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 30) && (long)p.M * p.ldc < (1L << 31) && (long)p.N * p.K < (1L << 30),
                 "igemm: tensor too large for 32-bit byte offsets");
     MTN_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.Wp | (uintptr_t)p.Out | (uintptr_t)p.res | (uintptr_t)p.aux_out) % 16 == 0, "igemm: pointers must be 16-byte aligned");
+    if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
     return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);
 }

@@ -33,6 +33,9 @@ struct IgemmArgs {
 
 int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_igemm_tiles_m(int M, int N, int K);
+bool mtn_dgrad2_ok(const IgemmArgs& p, int dtype);      // dgrad2.hip: all four parities of a 3x3 stride-2 data gradient per workgroup
+int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream);
+void mtn_dgrad2_set(int on);
 
 struct WgradArgs {
     const void* dY; int lddy;     // [M][lddy] output-pixel gradients

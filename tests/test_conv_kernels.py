@@ -27,9 +27,11 @@ def stages(request, be):
     from hand_gesture_recognition_amd import lib
     lib.call("mtn_debug_set", 3, request.param)
     lib.call("mtn_debug_set", 9, 150)       # every stride-1 3x3 shape goes through the window path
+    lib.call("mtn_debug_set", 15, 0)        # stride-2 data gradients through igemm's parity-major rows (dgrad2 has its own test)
     yield request.param
     lib.call("mtn_debug_set", 3, 5)
     lib.call("mtn_debug_set", 9, 0)
+    lib.call("mtn_debug_set", 15, 1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -149,6 +151,39 @@ def test_conv_dgrad(be, stages, dtype, cfg):
     ops.conv_dgrad(dy.to(be.device), pack_crsk(w, dtype).to(be.device), dx, dx, k, s)
     be.sync()
     assert rel_err(dx.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout        (3x3 stride 2; dgrad2 needs Cout % 128 == 0 in bf16, % 64 in fp32)
+    (1, 8, 8, 64, 128),          # one tile, one channel slab
+    (1, 10, 6, 64, 128),         # odd dy height / width (5 x 3)
+    (3, 12, 20, 128, 256),       # two row tiles (180 dy pixels), two column tiles, two channel slabs (bf16) / four (fp32)
+    (2, 2, 2, 64, 128),          # 1 x 1 dy: every neighbour is padding
+    (5, 16, 16, 64, 128),        # rows cross image borders inside a tile
+])
+def test_conv_dgrad_stride2_fused(be, dtype, with_res, cfg):
+    """dgrad2.hip (all four output parities per workgroup) against autograd, writing into a channel
+    slice of a wider gradient buffer and reading dy from one."""
+    B, H, W, Cin, Cout = cfg
+    w = _rand((Cout, Cin, 3, 3), torch.float32, 15) / (Cout * 9) ** 0.5
+    wq = w.to(dtype).float()
+    x = torch.zeros((B, Cin, H, W), requires_grad=True)
+    yref = F.conv2d(x, wq, None, 2, 1)
+    dy_wide = _rand(tuple(yref.permute(0, 2, 3, 1).shape[:3]) + (2 * Cout,), dtype, 16)
+    dy = dy_wide[..., Cout:]
+    res = _rand((B, H, W, Cin), dtype, 17)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1) + (res.float() if with_res else 0)
+    wide = torch.full((B, H, W, 2 * Cin), 7.0, dtype=dtype, device=be.device)
+    dx = wide[..., :Cin]
+    if with_res:
+        dx.copy_(res.to(be.device))
+    ops.conv_dgrad(dy_wide.to(be.device)[..., Cout:], pack_crsk(w, dtype).to(be.device), dx, dx if with_res else None, 3, 2)
+    be.sync()
+    assert rel_err(dx.float(), ref) < tol(dtype)
+    assert float((wide[..., Cin:].float() - 7.0).abs().max()) == 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--igemm_dbg", type=int, default=0)
     ap.add_argument("--wgrad_slots", type=int, default=0)
     ap.add_argument("--conv1_px", type=int, default=0)
+    ap.add_argument("--key", action="append", default=[], help="K=V: mtn_debug_set(K, V) before the runs (repeatable)")
     ap.add_argument("--win_limit", type=int, default=0, help="window-mode LDS limit in KB (default 53)")
     ap.add_argument("--lib", default="", help="A/B: load this build of the library instead of libmtn_hip.so")
     a = ap.parse_args()
@@ -52,6 +53,9 @@ def main():
     _lib.call("mtn_debug_set", 6, a.igemm_tile)
     _lib.call("mtn_debug_set", 7, a.wgrad_tile)
     _lib.call("mtn_debug_set", 8, a.igemm_dbg)
+    for kv in a.key:
+        k, v = kv.split("=")
+        _lib.call("mtn_debug_set", int(k), int(v))
     try:
         _lib.call("mtn_debug_set", 10, a.wgrad_slots)
     except RuntimeError:
