@@ -140,21 +140,12 @@ template <class T, int VEC>
 __device__ __forceinline__ void bn_dz(const T* __restrict__ dout, int lddo, const T* __restrict__ y, int ldy,
                                       const T* __restrict__ res, int ldr, const ChanConst<VEC>& ss,
                                       const ChanConst<VEC>& mr, int act, int m, int c, float* dz, float* xh) {
-    float g[VEC], v[VEC];
+    float g[VEC], v[VEC], r[VEC];
     unpack<T>(*reinterpret_cast<const chunk16*>(dout + (long)m * lddo + c), g);
     unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
-    MTN_UNROLL for (int e = 0; e < VEC; ++e) xh[e] = (v[e] - mr.a[e]) * mr.b[e];
-    if (act == MTN_ACT_SILU) {
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * ss.a[e] + ss.b[e];
-        if (res) {
-            float r[VEC];
-            unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += r[e];
-        }
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] = g[e] * silu_grad_(v[e]);
-    } else {
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] = g[e];
-    }
+    const bool with_res = act == MTN_ACT_SILU && res;
+    if (with_res) unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
+    bn_dz_math<VEC>(g, v, r, with_res, ss.a, ss.b, mr.a, mr.b, act == MTN_ACT_SILU, dz, xh);
 }
 
 // partial[blockIdx.x][2][C]: sum dz, sum dz*xhat over this block's rows
@@ -332,10 +323,13 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
     MTN_REQUIRE(a.C % vec == 0 && cpr <= 256 && 256 % cpr == 0, "bn_bwd: C=%d unsupported", a.C);
     MTN_REQUIRE(a.act == MTN_ACT_NONE || a.act == MTN_ACT_SILU, "bn_bwd: act=%d", a.act);
     MTN_REQUIRE(a.act == MTN_ACT_SILU || !a.res, "bn_bwd: residual needs SiLU");
-    const int blocks = mtn_bn_bwd_blocks(a.M);
+    MTN_REQUIRE(a.partial_rows >= 0, "bn_bwd: partial_rows=%d", a.partial_rows);
+    const int blocks = a.partial_rows > 0 ? a.partial_rows : mtn_bn_bwd_blocks(a.M);
     const int rows_per_block = mtn_cdiv(a.M, blocks);
     const size_t lds = (size_t)(256 / cpr) * 2 * a.C * sizeof(float);
-    if (dtype == MTN_BF16)
+    if (a.partial_rows > 0) {
+        // the data gradient that wrote dout left the sums in partial (igemm.hip / dgrad2.hip epilogue)
+    } else if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)a.dout, a.lddo,
                    (const bf16_t*)a.y, a.ldy, (const bf16_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
                    rows_per_block, a.partial);

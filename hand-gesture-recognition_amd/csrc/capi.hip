@@ -25,7 +25,7 @@ int mtn_check_launch(const char* what) {
 extern "C" {
 
 const char* mtn_last_error(void) { return g_err; }
-int mtn_abi_version(void) { return 2; }
+int mtn_abi_version(void) { return 3; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
@@ -47,14 +47,10 @@ int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float*
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
-int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res,
-                   int ldres, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
-                   int stride, void* stream) {
-    MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_dgrad: ksize=%d", ksize);
-    MTN_REQUIRE(stride == 1 || stride == 2, "conv_dgrad: stride=%d", stride);
+static int conv_dgrad_args(IgemmArgs& p, const char* who, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    MTN_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize=%d", who, ksize);
+    MTN_REQUIRE(stride == 1 || stride == 2, "%s: stride=%d", who, stride);
     const int pad = ksize / 2;
-    IgemmArgs p{};
-    p.A = dy; p.Wp = wt; p.Out = dx; p.lda = lddy; p.ldc = lddx;
     p.B = B;
     p.H = (H + 2 * pad - ksize) / stride + 1;     // gather source = dy
     p.W = (W + 2 * pad - ksize) / stride + 1;
@@ -63,8 +59,40 @@ int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
     p.KH = p.KW = ksize;
     p.mul = 1; p.sgn = -1; p.off = pad; p.div = stride;
     p.M = B * H * W; p.N = Cin; p.K = ksize * ksize * Cout;
-    p.res = res; p.ldr = ldres;
     p.pm = (stride == 2 && ksize == 3 && H % 2 == 0 && W % 2 == 0) ? 1 : 0;
+    return MTN_OK;
+}
+
+int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res,
+                   int ldres, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                   int stride, void* stream) {
+    IgemmArgs p{};
+    const int rc = conv_dgrad_args(p, "conv_dgrad", B, H, W, Cin, Cout, ksize, stride);
+    if (rc) return rc;
+    p.A = dy; p.Wp = wt; p.Out = dx; p.lda = lddy; p.ldc = lddx;
+    p.res = res; p.ldr = ldres;
+    return mtn_igemm_run(p, dtype, (hipStream_t)stream);
+}
+
+int mtn_conv_dgrad_bn_tiles(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    IgemmArgs p{};
+    if (conv_dgrad_args(p, "conv_dgrad_bn_tiles", B, H, W, Cin, Cout, ksize, stride)) return -1;
+    return mtn_igemm_stats_tiles(p, dtype);
+}
+
+int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res, int ldres,
+                      const void* bn_y, int bn_ldy, const void* bn_res, int bn_ldres, const float* bn_scale_shift,
+                      const float* bn_mean_rstd, int bn_act, float* bn_partial, int bn_tiles, int dtype, int B, int H,
+                      int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+    IgemmArgs p{};
+    const int rc = conv_dgrad_args(p, "conv_dgrad_bn", B, H, W, Cin, Cout, ksize, stride);
+    if (rc) return rc;
+    MTN_REQUIRE(bn_y && bn_scale_shift && bn_mean_rstd && bn_partial, "conv_dgrad_bn: null BatchNorm operand");
+    p.A = dy; p.Wp = wt; p.Out = dx; p.lda = lddy; p.ldc = lddx;
+    p.res = res; p.ldr = ldres;
+    p.bn_y = bn_y; p.bn_ldy = bn_ldy; p.bn_res = bn_res; p.bn_ldr = bn_ldres;
+    p.bn_ss = bn_scale_shift; p.bn_mr = bn_mean_rstd; p.bn_act = bn_act;
+    p.stats = bn_partial; p.stats_rows = bn_tiles;
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
@@ -184,8 +212,9 @@ int mtn_bn_bwd_partial_rows(int M) { return mtn_reduce_rows_needed(mtn_bn_bwd_bl
 int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
                    const float* scale_shift, const float* mean_rstd, float* partial, float* coef,
                    float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
-                   const void* extra, int ldextra, int dtype, int M, int C, int act, void* stream) {
+                   const void* extra, int ldextra, int partial_rows, int dtype, int M, int C, int act, void* stream) {
     BnBwdArgs a{};
+    a.partial_rows = partial_rows;
     a.dout = dout; a.lddo = lddo; a.y = y; a.ldy = ldy; a.res = res; a.ldr = ldres;
     a.scale_shift = scale_shift; a.mean_rstd = mean_rstd; a.partial = partial; a.coef = coef;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.lddy = lddy; a.dres = dres; a.lddres = lddres;

@@ -38,8 +38,9 @@ void dgrad2_kernel(IgemmArgs p) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KI = Mma<T>::KI, KS = BK / KI, NS = CS * KS;
     constexpr int FM = 2, FN = 2;
-    constexpr int CPR = 2 * BN / VEC;                   // 16-byte chunks of one staged row (both x parities)
-    constexpr int CP = 2 * BN + 16 / (int)sizeof(T);    // its pitch in elements
+    constexpr int NQ = sizeof(T) == 2 ? 2 : 1;          // output-row parities staged per epilogue round
+    constexpr int CPR = NQ * 2 * BN / VEC;              // 16-byte chunks of one staged row ([qy][qx][n])
+    constexpr int CP = NQ * 2 * BN + 16 / (int)sizeof(T);   // its pitch in elements
     static_assert(NT % CPR == 0, "store mapping");
 
     MTN_DYN_SMEM(smem);
@@ -49,7 +50,7 @@ void dgrad2_kernel(IgemmArgs p) {
     T* const sW = reinterpret_cast<T*>(smem);           // [2 stages][CS][BN][BK]
     T* const sWin = sW + 2 * CS * BN * BK;              // [CS][WR8][BK]
     const int zero_off = CS * WR8 * BK;                 // (relative to sWin) one zero row
-    T* const sC = reinterpret_cast<T*>(smem);           // [BM][CP] per output-row parity (after the K loop)
+    T* const sC = reinterpret_cast<T*>(smem);           // [BM][CP] staged classes (after the K loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 3, wn = wid >> 2;
@@ -163,33 +164,91 @@ void dgrad2_kernel(IgemmArgs p) {
         tap_step(std::integral_constant<int, 8>{}, slab);
     }
 
-    // ---- epilogue: per output-row parity qy, both x parities staged as [row][qx][n] -> 16-byte stores ----
+    // ---- epilogue: classes staged as [row][qy][qx][n] -> 16-byte stores (both x parities of an output row are adjacent) ----
+    // bf16: all four classes in one round; fp32: one output-row parity per round (LDS).  A thread keeps ONE
+    // (qy, qx, channel chunk) for all its rows.
     T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
     const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
     const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
-    const int qx = ccol / BN, col = ccol - qx * BN;
-    MTN_UNROLL for (int qy = 0; qy < 2; ++qy) {
-        if (qy) __syncthreads();
-        MTN_UNROLL for (int x = 0; x < 2; ++x)
-            MTN_UNROLL for (int i = 0; i < FM; ++i)
-                MTN_UNROLL for (int j = 0; j < FN; ++j)
-                    store4<T>(sC + (wm * 32 + i * 16 + frow) * CP + x * BN + wn * 32 + j * 16 + 4 * (lane >> 4), acc[qy * 2 + x][i][j]);
+    const int qyl = ccol / (2 * BN), qx = (ccol / BN) & 1, col = ccol % BN;
+    constexpr int RPT = BM / (NT / CPR);
+    // BatchNorm backward sums of the unit whose output gradient dx is (IgemmArgs::bn_y), as in igemm.hip
+    const T* __restrict__ gBy = reinterpret_cast<const T*>(p.bn_y);
+    const T* __restrict__ gBr = reinterpret_cast<const T*>(p.bn_res);
+    float st_s[VEC], st_q[VEC];
+    MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+    MTN_UNROLL for (int r = 0; r < 2 / NQ; ++r) {
+        if (r) __syncthreads();
+        MTN_UNROLL for (int q = 0; q < NQ; ++q)
+            MTN_UNROLL for (int x = 0; x < 2; ++x)
+                MTN_UNROLL for (int i = 0; i < FM; ++i)
+                    MTN_UNROLL for (int j = 0; j < FN; ++j)
+                        store4<T>(sC + (wm * 32 + i * 16 + frow) * CP + (q * 2 + x) * BN + wn * 32 + j * 16 + 4 * (lane >> 4),
+                                  acc[(r * NQ + q) * 2 + x][i][j]);
+        // (the accumulators of this round are dead now: room for the row prefetch)
+        // this thread's rows: pixel (b, 2a + qy, 2c + qx) of each, -1 beyond Md
+        const int qy = r * NQ + qyl;
+        int opix[RPT];
+        MTN_UNROLL for (int i = 0; i < RPT; ++i) {
+            const int m = m0 + trow + i * (NT / CPR);
+            int b = 0, a = 0, c = 0;
+            if (m < Md) decode(m, b, a, c);
+            opix[i] = m < Md ? (b * p.OH + 2 * a + qy) * p.OW + 2 * c + qx : -1;
+        }
+        // raw-output chunks of the BatchNorm unit: in flight across the barrier and the first rows
+        chunk16 bn_yv[RPT];
+        if (gBy) {
+            MTN_UNROLL for (int i = 0; i < RPT; ++i) {
+                const long o = opix[i] < 0 ? 0 : opix[i];
+                bn_yv[i] = *reinterpret_cast<const chunk16*>(gBy + o * p.bn_ldy + n0 + col);
+            }
+        }
         __syncthreads();
-        for (int row = trow; row < BM; row += NT / CPR) {
-            const int m = m0 + row;
-            if (m >= Md) break;
-            int b, a, c;
-            decode(m, b, a, c);
-            const long o = (long)(b * p.OH + 2 * a + qy) * p.OW + 2 * c + qx;
+        float bn_sc[VEC], bn_sh[VEC], bn_mu[VEC], bn_rs[VEC];
+        if (gBy) {
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+                bn_sc[e] = p.bn_ss[n0 + col + e]; bn_sh[e] = p.bn_ss[p.N + n0 + col + e];
+                bn_mu[e] = p.bn_mr[n0 + col + e]; bn_rs[e] = p.bn_mr[p.N + n0 + col + e];
+            }
+        }
+        MTN_UNROLL for (int i = 0; i < RPT; ++i) {
+            if (opix[i] < 0) continue;
+            const int row = trow + i * (NT / CPR);
+            const long o = opix[i];
             chunk16 v = *reinterpret_cast<const chunk16*>(sC + row * CP + ccol);
             if (gR) {
-                float f[VEC], r[VEC];
+                float f[VEC], rr[VEC];
                 unpack<T>(v, f);
-                unpack<T>(*reinterpret_cast<const chunk16*>(gR + o * p.ldr + n0 + col), r);
-                MTN_UNROLL for (int e = 0; e < VEC; ++e) f[e] += r[e];
+                unpack<T>(*reinterpret_cast<const chunk16*>(gR + o * p.ldr + n0 + col), rr);
+                MTN_UNROLL for (int e = 0; e < VEC; ++e) f[e] += rr[e];
                 v = pack<T>(f);
             }
             *reinterpret_cast<chunk16*>(gO + o * p.ldc + n0 + col) = v;
+            if (gBy) {
+                float w[VEC], yv[VEC], rr[VEC], dz[VEC], xh[VEC];
+                unpack<T>(v, w);
+                unpack<T>(bn_yv[i], yv);
+                if (gBr) unpack<T>(*reinterpret_cast<const chunk16*>(gBr + o * p.bn_ldr + n0 + col), rr);
+                bn_dz_math<VEC>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
+                MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
+            }
+        }
+    }
+    if (gBy) {
+        constexpr int TRN = NT / CPR, RW = NQ * 2 * BN;
+        __syncthreads();                                   // everyone is done reading the staged tile
+        float* red = reinterpret_cast<float*>(smem);       // [2][TRN][RW]
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+            red[trow * RW + ccol + e] = st_s[e];
+            red[(TRN + trow) * RW + ccol + e] = st_q[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) {
+            const int which = i / BN, cc = i - which * BN;
+            float t = 0.f;
+            for (int q = 0; q < TRN; ++q)
+                MTN_UNROLL for (int x = 0; x < NQ * 2; ++x) t += red[(which * TRN + q) * RW + x * BN + cc];
+            p.stats[((long)tile_m * 2 + which) * p.N + n0 + cc] = t;
         }
     }
 }
@@ -197,7 +256,7 @@ void dgrad2_kernel(IgemmArgs p) {
 size_t dgrad2_lds(const IgemmArgs& p, int esz) {
     const size_t wr8 = (size_t)((D2_BM + p.W + 1 + 7) & ~7);
     const size_t loop = (2 * (size_t)D2_BN + wr8) * D2_CS * 128 + 128;
-    const size_t epi = (size_t)D2_BM * (2 * D2_BN * esz + 16);
+    const size_t epi = (size_t)D2_BM * ((esz == 2 ? 2 : 1) * 2 * D2_BN * esz + 16);
     return loop > epi ? loop : epi;
 }
 
@@ -210,7 +269,10 @@ int launch_dgrad2(const IgemmArgs& p, hipStream_t stream) {
     static MtnLdsAttr attr;
     mtn_set_max_lds(attr, &dgrad2_kernel<T>, 80 * 1024);
 #endif
-    const long tiles = (long)mtn_cdiv((long)p.B * p.H * p.W, D2_BM) * (p.N / D2_BN);
+    const int tiles_m = mtn_cdiv((long)p.B * p.H * p.W, D2_BM);
+    MTN_REQUIRE(!p.stats || p.stats_rows == tiles_m, "dgrad2: the statistics slab was sized for %d row tiles, this launch writes %d",
+                p.stats_rows, tiles_m);
+    const long tiles = (long)tiles_m * (p.N / D2_BN);
     MTN_LAUNCH(dgrad2_kernel<T>, dim3((unsigned)tiles), dim3(D2_NT), lds, stream, p);
     return mtn_check_launch("dgrad2");
 }
@@ -223,9 +285,11 @@ void mtn_dgrad2_set(int on) { g_dgrad2 = on ? 1 : 0; }
 bool mtn_dgrad2_ok(const IgemmArgs& p, int dtype) {
     const int esz = dtype == MTN_BF16 ? 2 : 4, bk = 128 / esz;
     return g_dgrad2 && p.pm && p.KH == 3 && p.KW == 3 && p.div == 2 && p.mul == 1 && p.sgn == -1 && p.off == 1 &&
-           p.OH == 2 * p.H && p.OW == 2 * p.W && p.Cin % (D2_CS * bk) == 0 && p.N % D2_BN == 0 && !p.bias && !p.stats &&
+           p.OH == 2 * p.H && p.OW == 2 * p.W && p.Cin % (D2_CS * bk) == 0 && p.N % D2_BN == 0 && !p.bias && (!p.stats || p.bn_y) &&
            p.act == MTN_ACT_NONE && !p.aux_out && dgrad2_lds(p, esz) <= 80 * 1024;
 }
+
+int mtn_dgrad2_tiles_m(const IgemmArgs& p) { return mtn_cdiv((long)p.B * p.H * p.W, D2_BM); }
 
 int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
     return dtype == MTN_BF16 ? launch_dgrad2<bf16_t>(p, stream) : launch_dgrad2<float>(p, stream);

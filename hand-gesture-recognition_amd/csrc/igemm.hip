@@ -524,6 +524,44 @@ void igemm_kernel(IgemmArgs p) {
     const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
     // ---- epilogue: accumulators -> LDS (f32) -> row-wise fused math -> 16-byte stores ----------
+    T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
+    T* __restrict__ gAux = reinterpret_cast<T*>(p.aux_out);
+    const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
+    constexpr int CPR = BN / VEC;     // chunks per row
+    constexpr int TR = NT / CPR;      // thread rows: a thread keeps ONE column chunk for all its rows
+    constexpr int RPT = BM / TR;      // rows per thread
+    static_assert(NT % CPR == 0 && BM % TR == 0, "store mapping");
+    const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
+    // output row of each of this thread's rows (-1: beyond M)
+    int orow[RPT];
+    MTN_UNROLL for (int i = 0; i < RPT; ++i) {
+        int m = m0 + trow + i * TR;
+        if (m >= p.M) m = -1;
+        else if (pm_) {
+            int b, oy, ox;
+            decode(m, b, oy, ox);
+            m = (b * p.OH + oy) * p.OW + ox;
+        }
+        orow[i] = m;
+    }
+    // Data gradient feeding a BatchNorm unit's backward (IgemmArgs::bn_y): that unit's per-channel constants
+    // for this thread's chunk, and its raw-output / residual chunks of this thread's rows -- requested HERE,
+    // before the accumulators are staged, so their latency hides behind the staging and its barrier.
+    const T* __restrict__ gBy = reinterpret_cast<const T*>(p.bn_y);
+    const T* __restrict__ gBr = reinterpret_cast<const T*>(p.bn_res);
+    float bn_sc[VEC], bn_sh[VEC], bn_mu[VEC], bn_rs[VEC];
+    chunk16 bn_yv[RPT], bn_rv[RPT];
+    if (gBy) {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+            bn_sc[e] = p.bn_ss[n0 + ccol + e]; bn_sh[e] = p.bn_ss[p.N + n0 + ccol + e];
+            bn_mu[e] = p.bn_mr[n0 + ccol + e]; bn_rs[e] = p.bn_mr[p.N + n0 + ccol + e];
+        }
+        MTN_UNROLL for (int i = 0; i < RPT; ++i) {
+            const long m = orow[i] < 0 ? 0 : orow[i];
+            bn_yv[i] = *reinterpret_cast<const chunk16*>(gBy + m * p.bn_ldy + n0 + ccol);
+            if (gBr) bn_rv[i] = *reinterpret_cast<const chunk16*>(gBr + m * p.bn_ldr + n0 + ccol);
+        }
+    }
     // The MFMAs take the W fragment as their row operand, so a lane's four accumulator registers
     // are four CONSECUTIVE channels of one pixel: one 8- / 16-byte LDS store per fragment instead
     // of four scattered element stores.
@@ -533,23 +571,12 @@ void igemm_kernel(IgemmArgs p) {
     __syncthreads();
     STAMP(st_e1);
 
-    T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
-    T* __restrict__ gAux = reinterpret_cast<T*>(p.aux_out);
-    const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
-    constexpr int CPR = BN / VEC;     // chunks per row
-    constexpr int TR = NT / CPR;      // thread rows: a thread keeps ONE column chunk for all its rows
-    static_assert(NT % CPR == 0, "store mapping");
-    const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
     float st_s[VEC], st_q[VEC];
     MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
-    for (int row = trow; row < BM; row += TR) {
-        int m = m0 + row;
-        if (m >= p.M) continue;
-        if (pm_) {
-            int b, oy, ox;
-            decode(m, b, oy, ox);
-            m = (b * p.OH + oy) * p.OW + ox;
-        }
+    MTN_UNROLL for (int i = 0; i < RPT; ++i) {
+        const int row = trow + i * TR;
+        const int m = orow[i];
+        if (m < 0) continue;
         float v[VEC];
         MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = to_f<CT>(sC[row * CP + ccol + e]);
         if (p.bias) {
@@ -569,7 +596,15 @@ void igemm_kernel(IgemmArgs p) {
         if (p.stats) {          // statistics of the values exactly as stored
             float w[VEC];
             unpack<T>(o, w);
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += w[e]; st_q[e] += w[e] * w[e]; }
+            if (gBy) {          // sum dz, sum dz*xhat of the BatchNorm unit whose output gradient this row is
+                float yv[VEC], rr[VEC], dz[VEC], xh[VEC];
+                unpack<T>(bn_yv[i], yv);
+                if (gBr) unpack<T>(bn_rv[i], rr);
+                bn_dz_math<VEC>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
+                MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
+            } else {
+                MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += w[e]; st_q[e] += w[e] * w[e]; }
+            }
         }
     }
     STAMP(st_e2);
@@ -739,6 +774,11 @@ int mtn_igemm_tiles_m(int M, int N, int K) {
     return mtn_cdiv(M, bm[igemm_config(M, N, K)]);
 }
 
+int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
+    if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_tiles_m(p);
+    return mtn_igemm_tiles_m(p.M, p.N, p.K);
+}
+
 int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     IgemmArgs p = p0;
     p.dbg = g_igemm_dbg;
@@ -758,8 +798,12 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.div == 1 || p.div == 2, "igemm: div=%d", p.div);
     MTN_REQUIRE(p.KH * p.KW <= 9, "igemm: at most 9 taps");
     MTN_REQUIRE(p.OH < 32768 && p.OW < 32768, "igemm: spatial size too large for the magic row decode");
-    MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && !p.stats && p.KH == 3 && p.KW == 3),
+    MTN_REQUIRE(!p.pm || (p.OH % 2 == 0 && p.OW % 2 == 0 && (!p.stats || p.bn_y) && p.KH == 3 && p.KW == 3),
                 "igemm: parity-major rows need a 3x3 tap set and even OH/OW");
+    MTN_REQUIRE(!p.bn_y || (p.stats && p.bn_ss && p.bn_mr && p.bn_ldy % (bk / 8) == 0 && (!p.bn_res || p.bn_ldr % (bk / 8) == 0) &&
+                            ((uintptr_t)p.bn_y | (uintptr_t)p.bn_res) % 16 == 0 &&
+                            (p.bn_act == MTN_ACT_SILU || (p.bn_act == MTN_ACT_NONE && !p.bn_res))),
+                "igemm: BatchNorm backward statistics need a slab, scale/shift, mean/rstd and aligned rows");
     MTN_REQUIRE((long)p.M * (p.pm ? p.OW / 2 : p.OW) < (1L << 32), "igemm: M * OW too large for the magic row decode");
     MTN_REQUIRE(p.lda % (bk / 8) == 0 && p.ldc % (bk / 8) == 0, "igemm: lda/ldc must keep 16-byte alignment");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "igemm: M=%d != B*OH*OW", p.M);

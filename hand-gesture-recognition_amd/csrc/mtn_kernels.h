@@ -24,6 +24,14 @@ struct IgemmArgs {
     int ldr;
     float* stats;         // [tiles_m][2][N] BN partial sums, or null
     int stats_rows;       // rows the caller allocated for stats: must equal the tile rows of the launch
+    // Data gradients only: Out is the OUTPUT gradient of a BatchNorm unit (raw conv output bn_y, pre-activation
+    // bn_y*scale+shift [+ bn_res]).  stats then receives that unit's backward sums -- sum dz, sum dz*xhat,
+    // dz = Out * act'(.) -- instead of sum / sum of squares: the reduce pass of its BN backward (bn.hip).
+    const void* bn_y; int bn_ldy;
+    const void* bn_res; int bn_ldr;
+    const float* bn_ss;   // [2][N] scale, shift
+    const float* bn_mr;   // [2][N] mean, rstd
+    int bn_act;
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
     unsigned magic_tn;           // filled at launch: multiply-high divisor of the tile index (N / BN)
@@ -35,6 +43,8 @@ int mtn_igemm_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_igemm_tiles_m(int M, int N, int K);
 bool mtn_dgrad2_ok(const IgemmArgs& p, int dtype);      // dgrad2.hip: all four parities of a 3x3 stride-2 data gradient per workgroup
 int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream);
+int mtn_dgrad2_tiles_m(const IgemmArgs& p);
+int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype);   // rows of the statistics slab this launch would write
 void mtn_dgrad2_set(int on);
 
 struct WgradArgs {
@@ -60,6 +70,8 @@ struct BnBwdArgs {
     const float* scale_shift;         // [2][C] from bn_finalize
     const float* mean_rstd;           // [2][C]
     float* partial;                   // [mtn_reduce_rows_needed(mtn_bn_bwd_blocks(M))][2][C]
+    int partial_rows;                 // 0: run the reduce pass; > 0: partial already holds that many rows of
+                                      // (sum dz, sum dz*xhat) -- written by the data gradient that produced dout
     float* coef;                      // [2][C] scratch
     float* dgamma; float* dbeta;      // [C] parameter gradients (overwritten)
     void* dy; int lddy;               // gradient of the raw conv output

@@ -252,6 +252,24 @@ __device__ __forceinline__ float gelu_grad_(float x) {
     return cdf + x * pdf;
 }
 
+// BatchNorm + activation backward, one 16-byte chunk: g = gradient of act(y*scale + shift [+ res]) as stored,
+// v = raw conv output y (overwritten), r = residual or null  ->  dz (pre-activation gradient), xh (xhat).
+// Shared by the BN backward passes (bn.hip) and the data-gradient epilogues that pre-reduce for them.
+template <int VEC>
+__device__ __forceinline__ void bn_dz_math(const float* g, float* v, const float* r, bool with_r, const float* scale, const float* shift,
+                                           const float* mean, const float* rstd, bool silu, float* dz, float* xh) {
+    MTN_UNROLL for (int e = 0; e < VEC; ++e) xh[e] = (v[e] - mean[e]) * rstd[e];
+    if (silu) {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * scale[e] + shift[e];
+        if (with_r) {
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += r[e];
+        }
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] = g[e] * silu_grad_(v[e]);
+    } else {
+        MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] = g[e];
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     MTN_UNROLL for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;

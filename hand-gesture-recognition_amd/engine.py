@@ -15,6 +15,8 @@ Data layout in HBM
 Reference op order: model/multitasknet.py:24-29 -> model/gelan.py:165-176 ->
 model/transformer.py:129-152; loss libs/loss.py + train.py:63-64,75.
 """
+import os
+
 import torch
 
 from . import ops
@@ -49,6 +51,8 @@ class Engine:
         # optional callback(tag) fired inside backward() as soon as a contiguous group of parameter
         # gradients is final: "head" (projection + decoder), ("stage", i), "stem" -- in that order
         self.on_grads_ready = None
+        # data gradients pre-reduce the BatchNorm backward of the unit they feed (MTN_FUSE_BN_BWD=0: two-pass backward)
+        self.fuse_bn_bwd = os.environ.get("MTN_FUSE_BN_BWD", "1") != "0"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -148,9 +152,13 @@ class Engine:
                 u.ss, u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout), self._f32(2, u.cout)
                 if u is not self.u_conv1:
                     max_part = max(max_part, ops.bn_bwd_partial_rows(M) * 2 * u.cout)
+            u.pre_rows = 0      # > 0: the data gradient that produced this unit's output gradient left that many rows of BN-backward sums in bn_part
             if u is self.u_conv1:
                 self.conv1_part = self._f32(*ops.conv1_bwd_partial_shape(B, self.H, self.W))
             else:
+                # rows of BatchNorm-backward sums this unit's data gradient writes for the unit consuming it (conv_dgrad(bn=...))
+                u.dgrad_tiles = ops.conv_dgrad_bn_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
+                max_part = max(max_part, ops.slab_rows(u.dgrad_tiles) * 2 * u.cin)
                 max_dy = max(max_dy, M * u.cout)
                 max_ws = max(max_ws, ops.conv_wgrad_workspace_bytes(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s))
         Mt = B * self.N
@@ -230,16 +238,32 @@ class Engine:
         ops.conv_fwd(x, u.wf, u.raw, u.stats if training else None, u.k, u.s, stats_tiles=u.tiles if u.bn else None)
         self._bn_fwd(u, out, training, res)
 
-    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True):
+    def _dgrad(self, u, dy, g_in, g_in_res=None, nxt=None):
+        """g_in = data gradient of unit ``u`` [+ g_in_res].  ``nxt`` = (unit, its residual input or None) when
+        g_in is, after this launch, the complete output gradient of that unit: the launch then also writes
+        the partial sums of that unit's BatchNorm backward (ops.conv_dgrad(bn=...)), which its _conv_bwd
+        -- always the next one to use bn_part -- consumes instead of running its own reduce pass."""
+        if nxt is None or not self.fuse_bn_bwd or not nxt[0].bn:
+            ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s)
+            return
+        n, nres = nxt
+        assert n.cout == u.cin and n.raw.shape == g_in.shape
+        ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s,
+                       bn=(n.raw, nres, n.ss, n.mr, _ACT[n.act or nres is not None], self.bn_part, u.dgrad_tiles))
+        n.pre_rows = u.dgrad_tiles
+
+    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True, nxt=None):
         """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res]).
         ``dres`` receives the gradient of the residual operand, added to its old contents unless
-        ``dres_accumulate`` is False."""
+        ``dres_accumulate`` is False.  ``nxt``: see _dgrad."""
         bn, dy = u.mod.bn, self._dy(u)
+        rows, u.pre_rows = u.pre_rows, 0
         ops.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
-                       dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None)
+                       dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
+                       partial_rows=rows)
         ops.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
         if g_in is not None:
-            ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s)
+            self._dgrad(u, dy, g_in, g_in_res, nxt)
 
     # ---------------------------------------------------------------- forward
     def backbone_forward(self, x, training=True):
@@ -329,7 +353,7 @@ class Engine:
             C, cat, gc = st["C"], st["cat"], st["g_cat"]
             h2 = C // 2
             if st["down"] is not None:
-                self._conv_bwd(st["down"], g_cur, st["out"], st["g_out"])
+                self._conv_bwd(st["down"], g_cur, st["out"], st["g_out"], nxt=(st["cv4"], None))
                 g_cur = st["g_out"]
             self._conv_bwd(st["cv4"], g_cur, cat, gc)
             # branches in reverse (cv3: y3 = blocks(y2), then cv2: y2 = blocks(y1)), blocks in reverse.
@@ -344,10 +368,25 @@ class Engine:
                     first = i == 0
                     xin = cat[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["o"]
                     g_xin = gc[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["g_o"]
-                    self._conv_bwd(rb["c2"], g_out, rb["t"], st["g_t"], res=xin, dres=g_xin, dres_accumulate=first)
-                    self._conv_bwd(rb["c1"], st["g_t"], xin, g_xin, g_in_res=g_xin)
-            g_in = self.g_a2 if st is self.stages[0] else self.stages[self.stages.index(st) - 1]["g_dn"]
-            self._conv_bwd(st["cv1"], gc[..., :C], st["in"], g_in)
+                    self._conv_bwd(rb["c2"], g_out, rb["t"], st["g_t"], res=xin, dres=g_xin, dres_accumulate=first,
+                                   nxt=(rb["c1"], None))
+                    # g_xin is complete after c1's data gradient, except the y1 slice of the concat (branch 0, first
+                    # block), which is only half of cv1's output gradient.  Its consumer: the previous block's c2,
+                    # or -- for the y2 slice (branch 1, first block) -- the last block of branch 0
+                    if not first:
+                        prev = br[i - 1]
+                        pxin = cat[..., h2 * (j + 1):h2 * (j + 2)] if i == 1 else br[i - 2]["o"]
+                        nxt = (prev["c2"], pxin)
+                    elif j == 1:
+                        b0 = st["branches"][0]
+                        nxt = (b0[-1]["c2"], cat[..., h2:2 * h2] if len(b0) == 1 else b0[-2]["o"])
+                    else:
+                        nxt = None
+                    self._conv_bwd(rb["c1"], st["g_t"], xin, g_xin, g_in_res=g_xin, nxt=nxt)
+            si = self.stages.index(st)
+            g_in = self.g_a2 if si == 0 else self.stages[si - 1]["g_dn"]
+            self._conv_bwd(st["cv1"], gc[..., :C], st["in"], g_in,
+                           nxt=(self.u_conv2 if si == 0 else self.stages[si - 1]["down"], None))
             g_cur = g_in
             self._ready(("stage", self.stages.index(st)))
         self._conv_bwd(self.u_conv2, self.g_a2, self.a1, self.g_a1)
@@ -360,6 +399,8 @@ class Engine:
         """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
         dlogits = self.dlogits if dlogits is None else dlogits
         dhm = self.dhm if dhm is None else dhm
+        for u in self.units:
+            u.pre_rows = 0          # (a backward that raised half-way must not leave a stale hand-over)
         dec, g = self.model.decoder, self._g
         B, N, D, Hh = self.B, self.N, self.dim, self.heads
         Mt = B * N
@@ -396,7 +437,7 @@ class Engine:
         up, last = self.u_proj, self.stages[-1]
         gf = self.g_feat.view(self.B, self.fh, self.fw, D)
         ops.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
-        ops.conv_dgrad(gf, up.wd, last["g_out"], None, 1, 1)
+        self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
         self._ready("head")
         self.backbone_backward(last["g_out"])
 

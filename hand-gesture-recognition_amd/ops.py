@@ -59,15 +59,33 @@ def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
              B, H, W, Cin, Cout, ksize, stride, _stream(x))
 
 
-def conv_dgrad(dy, wt, dx, res, ksize, stride):
-    """dy [B,OH,OW,Cout] -> dx [B,H,W,Cin] (+ res, which may alias dx)."""
+def conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
+    return lib.call("mtn_conv_dgrad_bn_tiles", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
+
+
+def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None):
+    """dy [B,OH,OW,Cout] -> dx [B,H,W,Cin] (+ res, which may alias dx).
+
+    ``bn`` = (y, res, scale_shift, mean_rstd, act, partial, tiles) of the Conv unit whose output gradient dx is: the
+    launch also writes that unit's BatchNorm-backward partial sums (``bn_act_bwd(..., partial_rows=tiles)``)."""
     B, H, W, Cin = dx.shape
     Cout = dy.shape[-1]
     dyp, lddy = _rows(dy)
     dxp, lddx = _rows(dx)
     rp, ldr = _rows(res) if res is not None else (0, 0)
-    lib.call("mtn_conv_dgrad", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, dtype_code(dy),
-             B, H, W, Cin, Cout, ksize, stride, _stream(dy))
+    if bn is None:
+        lib.call("mtn_conv_dgrad", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, dtype_code(dy),
+                 B, H, W, Cin, Cout, ksize, stride, _stream(dy))
+        return
+    y, bres, ss, mr, act, partial, tiles = bn
+    if tuple(y.shape) != tuple(dx.shape) or y.dtype != dx.dtype or (bres is not None and tuple(bres.shape) != tuple(dx.shape)):
+        raise ValueError("conv_dgrad: the BatchNorm unit's raw output / residual must have the shape and dtype of dx")
+    if partial.dtype != torch.float32 or partial.numel() < slab_rows(tiles) * 2 * Cin:
+        raise ValueError(f"conv_dgrad: BatchNorm partial slab too small for {tiles} row tiles")
+    yp, ldy = _rows(y)
+    brp, ldbr = _rows(bres) if bres is not None else (0, 0)
+    lib.call("mtn_conv_dgrad_bn", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, yp, ldy, brp, ldbr, ss.data_ptr(),
+             mr.data_ptr(), act, partial.data_ptr(), tiles, dtype_code(dy), B, H, W, Cin, Cout, ksize, stride, _stream(dy))
 
 
 def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None):
@@ -145,7 +163,7 @@ def bn_bwd_partial_rows(M):
 
 
 def bn_act_bwd(dout, y, res, scale_shift, mean_rstd, partial, coef, dgamma, dbeta, dy, act,
-               dres=None, extra=None):
+               dres=None, extra=None, partial_rows=0):
     C = y.shape[-1]
     M = y.numel() // C
     dop, lddo = _rows(dout)
@@ -156,7 +174,7 @@ def bn_act_bwd(dout, y, res, scale_shift, mean_rstd, partial, coef, dgamma, dbet
     ep, lde = _rows(extra) if extra is not None else (0, 0)
     lib.call("mtn_bn_act_bwd", dop, lddo, yp, ldy, rp, ldr, scale_shift.data_ptr(),
              mean_rstd.data_ptr(), partial.data_ptr(), coef.data_ptr(), dgamma.data_ptr(),
-             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, dtype_code(y), M, C, act, _stream(y))
+             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, partial_rows, dtype_code(y), M, C, act, _stream(y))
 
 
 def conv1_stats_tiles(B, H, W):

@@ -56,6 +56,21 @@ int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
                    const void* res, int ldres, int dtype, int B, int H, int W, int Cin, int Cout,
                    int ksize, int stride, void* stream);
 
+/* The same data gradient when dx [+ res] is the OUTPUT gradient of another Conv unit
+ * act(bn(conv)) [+ its residual] (model/gelan.py:56,78-87; in the backward pass nearly every dx is):
+ * while each tile of dx is still on chip its epilogue also reads that unit's raw conv output bn_y
+ * (same [B][H][W][Cin] rows as dx) and writes the partial sums of its BatchNorm backward --
+ * sum dz, sum dz*xhat with dz = dx * act'(bn_y*scale + shift [+ bn_res]) -- to
+ * bn_partial[bn_tiles][2][Cin] (allocate mtn_slab_rows(bn_tiles) rows).  mtn_bn_act_bwd called with
+ * partial_rows = bn_tiles then skips its own reduce pass over (dout, y): one read of dx and one
+ * launch less per layer.  bn_tiles must equal mtn_conv_dgrad_bn_tiles(...) (checked). */
+int mtn_conv_dgrad_bn_tiles(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res,
+                      int ldres, const void* bn_y, int bn_ldy, const void* bn_res, int bn_ldres,
+                      const float* bn_scale_shift, const float* bn_mean_rstd, int bn_act,
+                      float* bn_partial, int bn_tiles, int dtype, int B, int H, int W, int Cin,
+                      int Cout, int ksize, int stride, void* stream);
+
 /* Stem Conv(3,64,k3,s2) (model/gelan.py:155): reads the NCHW fp32 image batch directly, writes
  * the NHWC raw output [B][H/2][W/2][64] + stats[mtn_conv1_stats_tiles][2][64]; w packed [64][3][3][3]
  * as (co, kh, kw, ci).  The image needs no gradient, so there is no conv1 dgrad. */
@@ -127,12 +142,15 @@ int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void*
 
 /* Backward of the above + BatchNorm: dout -> dy (gradient of the raw conv output), dgamma, dbeta;
  * dres (optional) = gradient of the residual input [+ extra].  partial: f32
- * [mtn_bn_bwd_partial_rows(M)][2][C]; coef: f32 [2][C] scratch. */
+ * [mtn_bn_bwd_partial_rows(M)][2][C]; coef: f32 [2][C] scratch.  partial_rows = 0: the sums are
+ * reduced here from (dout, y); partial_rows > 0: partial already holds that many rows of them
+ * (mtn_conv_dgrad_bn wrote dout and the sums; the slab has mtn_slab_rows(partial_rows) rows). */
 int mtn_bn_bwd_partial_rows(int M);
 int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
                    const float* scale_shift, const float* mean_rstd, float* partial, float* coef,
                    float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
-                   const void* extra, int ldextra, int dtype, int M, int C, int act, void* stream);
+                   const void* extra, int ldextra, int partial_rows, int dtype, int M, int C, int act,
+                   void* stream);
 
 /* ---- ViT encoder (model/transformer.py), dim 256 ------------------------------------------------ */
 

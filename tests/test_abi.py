@@ -30,6 +30,6 @@ def test_library_exports_every_declared_symbol(which):
     for name in _declared():
         assert hasattr(dll, name), name
     lib.use_library(path)                     # binds all prototypes; raises on a missing symbol
-    assert lib.call("mtn_abi_version") == 2
+    assert lib.call("mtn_abi_version") == 3
     with pytest.raises(RuntimeError, match="ksize"):
         lib.call("mtn_conv_fwd", 0, 0, 0, 0, 0, 0, 0, 0, 1, 8, 8, 64, 64, 5, 1, 0)   # argument check, no launch

@@ -106,3 +106,76 @@ def test_bias_grad_many_slab_rows(be):
     ops.bias_grad(x.to(d), part, db)
     be.sync()
     assert rel_err(db, x.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fused_s2", [1, 0], ids=["dgrad2", "igemm"])
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, k, s, act, dgrad residual, BatchNorm-unit residual
+    (2, 6, 6, 64, 64, 3, 1, True, False, False),
+    (3, 5, 7, 128, 128, 1, 1, True, True, True),        # the c1 -> first-block c2 hand-over (both residuals)
+    (2, 9, 6, 64, 256, 3, 1, False, False, False),      # unit without activation
+    (1, 8, 8, 64, 128, 3, 2, True, False, False),       # stride 2 (dgrad2 / parity-major rows)
+    (3, 12, 20, 128, 256, 3, 2, True, True, False),     # stride 2, several tiles
+    (2, 12, 12, 256, 64, 1, 1, True, False, True),
+])
+def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
+    """mtn_conv_dgrad_bn: dx equals the plain data gradient, its slab sums to (sum dz, sum dz*xhat) of
+    the unit consuming dx, and bn_act_bwd(partial_rows=tiles) equals the two-pass backward."""
+    from hand_gesture_recognition_amd import lib
+    B, H, W, Cin, Cout, k, s, act, with_res, with_bres = cfg
+    if s == 1 and not fused_s2:
+        pytest.skip("the switch only matters for stride 2")
+    d = be.device
+    w = _rand((Cout, Cin, k, k), torch.float32, 41) / (Cout * k * k) ** 0.5
+    wt = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(d)
+    OH, OW = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    dy = _rand((B, OH, OW, Cout), dtype, 42).to(d)
+    res = _rand((B, H, W, Cin), dtype, 43).to(d) if with_res else None
+    y = (_rand((B, H, W, Cin), dtype, 44, 2.0) + 0.5).to(d)                 # raw conv output of the consuming unit
+    bres = _rand((B, H, W, Cin), dtype, 45).to(d) if with_bres else None
+    gamma = (1 + 0.2 * _rand((Cin,), torch.float32, 46)).to(d)
+    beta = (0.1 * _rand((Cin,), torch.float32, 47)).to(d)
+    M = B * H * W
+    yf = y.float().reshape(M, Cin)
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    ss = torch.stack([gamma * rstd, beta - mean * gamma * rstd]).contiguous()
+    mr = torch.stack([mean, rstd]).contiguous()
+    a = ops.ACT_SILU if act else ops.ACT_NONE
+    lib.call("mtn_debug_set", 15, fused_s2)
+    try:
+        dx_ref = torch.empty((B, H, W, Cin), dtype=dtype, device=d)
+        ops.conv_dgrad(dy, wt, dx_ref, res, k, s)
+        tiles = ops.conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, k, s)
+        part = torch.full((ops.slab_rows(tiles), 2, Cin), float("nan"), device=d)
+        dx = torch.empty_like(dx_ref)
+        ops.conv_dgrad(dy, wt, dx, res, k, s, bn=(y, bres, ss, mr, a, part, tiles))
+        be.sync()
+    finally:
+        lib.call("mtn_debug_set", 15, 1)
+    assert torch.equal(dx, dx_ref)
+    g = dx.float().reshape(M, Cin)
+    pre = yf * ss[0] + ss[1] + (bres.float().reshape(M, Cin) if with_bres else 0)
+    sg = torch.sigmoid(pre)
+    dz = g * (sg * (1 + pre * (1 - sg))) if act else g
+    xh = (yf - mean) * rstd
+    got = part[:tiles].sum(0)
+    assert rel_err(got[0], dz.sum(0)) < 2e-4 or float((got[0] - dz.sum(0)).abs().max()) < 2e-3
+    assert rel_err(got[1], (dz * xh).sum(0)) < 2e-4 or float((got[1] - (dz * xh).sum(0)).abs().max()) < 2e-3
+    # the BatchNorm backward from these sums == the backward that reduces them itself
+    outs = []
+    for rows, slab in ((tiles, part), (0, torch.empty(ops.bn_bwd_partial_rows(M), 2, Cin, device=d))):
+        coef = torch.empty(2, Cin, device=d)
+        dg, db = torch.empty(Cin, device=d), torch.empty(Cin, device=d)
+        dyo = torch.empty((B, H, W, Cin), dtype=dtype, device=d)
+        dres = torch.empty_like(dyo) if with_bres else None
+        ops.bn_act_bwd(dx, y, bres, ss, mr, slab, coef, dg, db, dyo, a, dres=dres, partial_rows=rows)
+        be.sync()
+        outs.append((dg.clone(), db.clone(), dyo.float().clone(), None if dres is None else dres.float().clone()))
+    (dg1, db1, dy1, dr1), (dg0, db0, dy0, dr0) = outs
+    scale = float(dg0.abs().max()) + float(db0.abs().max()) + 1e-6
+    assert float((dg1 - dg0).abs().max()) < 1e-4 * scale and float((db1 - db0).abs().max()) < 1e-4 * scale
+    assert rel_err(dy1, dy0) < tol(dtype, 1e-5, 1e-2)
+    if with_bres:
+        assert torch.equal(dr1, dr0)
