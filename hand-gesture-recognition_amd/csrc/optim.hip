@@ -51,6 +51,29 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
     const int* d = desc + blockIdx.y * 6;
     const int so = d[0], dof = d[1], O = d[2], I = d[3], taps = d[4], mode = d[5];
     const int n = O * I * taps;
+    if (mode == 1) {
+        // dst[i][tap][o] is the TRANSPOSE of the source matrix [O][I*taps]: 64 x 64 tiles through LDS, so
+        // that both the fp32 reads and the T writes run along contiguous rows (an element-wise gather
+        // touches a different 128-byte line per lane: 32x the bytes through the memory-side cache)
+        __shared__ float tile[64][65];
+        const int R = O, Cn = I * taps;
+        const int tc = (Cn + 63) / 64, nt = ((R + 63) / 64) * tc;
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+            const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+            MTN_UNROLL for (int k = 0; k < 16; ++k) {
+                const int r = r0 + ty + 4 * k, c = c0 + tx;
+                tile[ty + 4 * k][tx] = (r < R && c < Cn) ? src[so + r * Cn + c] : 0.f;
+            }
+            __syncthreads();
+            MTN_UNROLL for (int k = 0; k < 16; ++k) {
+                const int c = c0 + ty + 4 * k, r = r0 + tx;
+                if (c < Cn && r < R) dst[dof + c * R + r] = from_f<T>(tile[tx][ty + 4 * k]);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // inner = the destination's fastest axis (I for [o][tap][i], O for [i][tap][o]); one runtime division
     // per element (by inner), the tap split is by a literal 1 or 9 (the model's kernels), generic otherwise
     const int inner = mode == 0 ? I : O;

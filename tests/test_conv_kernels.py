@@ -376,3 +376,27 @@ def _conv1_fused_case(be, dtype, B, H, W):
     be.sync()
     assert rel_err(dg, gr.grad) < tol(dtype, 2e-4, 2e-2) and rel_err(db, br.grad) < tol(dtype, 2e-4, 2e-2)
     assert rel_err(dw, wr.grad) < tol(dtype, 5e-4, 3e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_weights_layouts(be, dtype):
+    """mtn_pack_weights: OIHW fp32 -> [O][kh][kw][I] (mode 0) and [I][kh][kw][O] (mode 1, tiled transpose) in T."""
+    shapes = [(64, 3, 3, 3), (128, 64, 3, 3), (96, 200, 1, 1), (256, 128, 1, 1), (70, 33, 3, 3)]
+    ws = [_rand(s, torch.float32, 60 + i) for i, s in enumerate(shapes)]
+    flat = torch.cat([w.flatten() for w in ws])
+    desc, off, src = [], 0, 0
+    for w in ws:
+        O, I, kh, kw = w.shape
+        for mode in (0, 1):
+            desc.append([src, off, O, I, kh * kw, mode])
+            off = (off + w.numel() + 7) & ~7
+        src += w.numel()
+    dst = torch.full((off,), float("nan"), dtype=dtype, device=be.device)
+    ops.pack_weights(flat.to(be.device), dst, torch.tensor(desc, dtype=torch.int32, device=be.device), len(desc),
+                     max(w.numel() for w in ws))
+    be.sync()
+    for j, w in enumerate(ws):
+        for mode in (0, 1):
+            o = desc[2 * j + mode][1]
+            want = (pack_krsc if mode == 0 else pack_crsk)(w, dtype).flatten()
+            assert torch.equal(dst[o:o + w.numel()].cpu(), want), (j, mode)
