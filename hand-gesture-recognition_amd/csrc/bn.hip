@@ -19,8 +19,8 @@ namespace {
 
 constexpr int kLanes = 16;            // row lanes of the 1024-thread reduction blocks (x 64 columns)
 
-// out[rb][c] = sum of in[r][c] over the rb-th block of rows_per_block rows
-__global__ __launch_bounds__(1024) void rowblock_sum_kernel(const float* __restrict__ in, int rows, int W,
+// out[rb][c] = sum of in[r][c] over the rb-th block of rows_per_block rows (in: row pitch ld >= W, out: dense)
+__global__ __launch_bounds__(1024) void rowblock_sum_kernel(const float* __restrict__ in, int rows, int W, int ld,
                                                             int rows_per_block, float* __restrict__ out) {
     __shared__ float red[kLanes][64];
     const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(1024) void rowblock_sum_kernel(const float* __restr
     if (r1 > rows) r1 = rows;
     float s = 0.f;
     if (c < W)
-        for (int r = r0 + tl; r < r1; r += kLanes) s += in[(long)r * W + c];
+        for (int r = r0 + tl; r < r1; r += kLanes) s += in[(long)r * ld + c];
     red[tl][cl] = s;
     __syncthreads();
     if (tl == 0 && c < W) {
@@ -262,16 +262,19 @@ int mtn_reduce_rows_needed(int rows) {
 // folds part[rows][W] 128 rows at a time into the scratch rows that follow it until a finalize
 // kernel takes the rest (16 row lanes x 64 columns per block); returns
 // pointer / row count of the slab the finalize kernel reads
-static int fold_rows(const float*& part, int& rows, int W, hipStream_t stream) {
+static int fold_rows(const float*& part, int& rows, int W, hipStream_t stream, int* ld_io = nullptr) {
+    int ld = ld_io ? *ld_io : W;                 // pitch of the producer's rows (>= W); folded rows are dense
     while (rows > kDirectRows) {
         const int R = mtn_cdiv(rows, kRowsPerBlock);
-        float* out = const_cast<float*>(part) + (long)rows * W;
-        MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(1024), 0, stream, part, rows, W, kRowsPerBlock, out);
+        float* out = const_cast<float*>(part) + (long)rows * ld;
+        MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), R), dim3(1024), 0, stream, part, rows, W, ld, kRowsPerBlock, out);
         int rc = mtn_check_launch("rowblock_sum");
         if (rc) return rc;
         part = out;
         rows = R;
+        ld = W;
     }
+    if (ld_io) *ld_io = ld;
     return MTN_OK;
 }
 
@@ -361,10 +364,15 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
 
 // generic ordered column sum of an f32 slab: out[c] = sum_r in[r][c]  (bias / LayerNorm affine grads)
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream) {
-    MTN_REQUIRE(rows > 0 && W > 0, "colsum: bad sizes (%d x %d)", rows, W);
+    return mtn_colsum_ld_run(slab, rows, W, W, out, stream);
+}
+
+// the same over the first W columns of rows with pitch ld (the scratch tail follows the ld-pitched rows)
+int mtn_colsum_ld_run(float* slab, int rows, int W, int ld, float* out, hipStream_t stream) {
+    MTN_REQUIRE(rows > 0 && W > 0 && ld >= W, "colsum: bad sizes (%d x %d, pitch %d)", rows, W, ld);
     const float* part = slab;
-    int rc = fold_rows(part, rows, W, stream);
+    int rc = fold_rows(part, rows, W, stream, &ld);
     if (rc) return rc;
-    MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), 1), dim3(1024), 0, stream, part, rows, W, rows, out);
+    MTN_LAUNCH(rowblock_sum_kernel, dim3(mtn_cdiv(W, 64), 1), dim3(1024), 0, stream, part, rows, W, ld, rows, out);
     return mtn_check_launch("colsum");
 }

@@ -109,6 +109,23 @@ int mtn_linear_fwd(const void* x, int ldx, const void* w, const float* bias, int
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
+int mtn_linear_gelu_bwd_tiles(int M, int N, int K) { return mtn_igemm_tiles_m(M, N, K); }
+
+int mtn_linear_gelu_bwd(const void* dh, int lddh, const void* wt, const void* a, int lda, void* da, int ldda,
+                        float* partial, int tiles, float* dbias, int dtype, int M, int N, int K, void* stream) {
+    MTN_REQUIRE(a && partial && dbias, "linear_gelu_bwd: null operand");
+    IgemmArgs p{};
+    p.A = dh; p.Wp = wt; p.Out = da; p.lda = lddh; p.ldc = ldda;
+    p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.KH = p.KW = 1;
+    p.mul = 1; p.sgn = 1; p.off = 0; p.div = 1;
+    p.M = M; p.N = N; p.K = K;
+    p.act = MTN_ACT_GELU_GRAD_; p.aux_out = const_cast<void*>(a); p.ld_aux = lda;
+    p.stats = partial; p.stats_rows = tiles;
+    const int rc = mtn_igemm_run(p, dtype, (hipStream_t)stream);
+    if (rc) return rc;
+    return mtn_colsum_ld_run(partial, tiles, N, 2 * N, dbias, (hipStream_t)stream);    // the sum half of each [2][N] row
+}
+
 static int conv_wgrad_args(WgradArgs& p, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
     const int pad = ksize / 2;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin;

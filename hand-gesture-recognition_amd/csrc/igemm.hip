@@ -100,9 +100,12 @@ void igemm_kernel(IgemmArgs p) {
     // order (every 1x1 conv and Linear: the tap machinery, the pixel decode and the parity-major
     // handling fold away -- 86 instead of 780 instructions before the first load of these short-K
     // tiles), 2 = 3x3 taps in natural row order, 3 = 3x3 taps in parity-major order.
-    constexpr bool PW = MODE == 1;
-    const int pm_ = (MODE == 1 || MODE == 2) ? 0 : (MODE == 3 ? 1 : p.pm);
-    const int KH_ = MODE == 1 ? 1 : (MODE >= 2 ? 3 : p.KH), KW_ = MODE == 1 ? 1 : (MODE >= 2 ? 3 : p.KW);
+    // 4 = mode 1 whose epilogue multiplies by gelu'(saved pre-activation) (MTN_ACT_GELU_GRAD_): its own
+    // instantiation, because the erf / exp of that epilogue cost every other one ~16 VGPRs (the 8-wave
+    // 128x128 tile then no longer fits two workgroups per CU).
+    constexpr bool PW = MODE == 1 || MODE == 4;
+    const int pm_ = (PW || MODE == 2) ? 0 : (MODE == 3 ? 1 : p.pm);
+    const int KH_ = PW ? 1 : (MODE >= 2 ? 3 : p.KH), KW_ = PW ? 1 : (MODE >= 2 ? 3 : p.KW);
     T* const sA = reinterpret_cast<T*>(smem);                       // [NBUF][BM][PITCH_E]  (WIN: unused)
     T* const sB = WIN ? sA : sA + NBUF * BM * PITCH_E;              // [NBUF][BN][PITCH_E]
     // WIN: window rows per channel slab (multiple of 8), resident 128-byte channel slabs, their
@@ -545,12 +548,12 @@ void igemm_kernel(IgemmArgs p) {
         orow[i] = m;
     }
     // Data gradient feeding a BatchNorm unit's backward (IgemmArgs::bn_y): that unit's per-channel constants
-    // for this thread's chunk, and its raw-output / residual chunks of this thread's rows -- requested HERE,
+    // for this thread's chunk, and its raw-output chunks of this thread's rows -- requested HERE,
     // before the accumulators are staged, so their latency hides behind the staging and its barrier.
     const T* __restrict__ gBy = reinterpret_cast<const T*>(p.bn_y);
     const T* __restrict__ gBr = reinterpret_cast<const T*>(p.bn_res);
     float bn_sc[VEC], bn_sh[VEC], bn_mu[VEC], bn_rs[VEC];
-    chunk16 bn_yv[RPT], bn_rv[RPT];
+    chunk16 bn_yv[RPT];
     if (gBy) {
         MTN_UNROLL for (int e = 0; e < VEC; ++e) {
             bn_sc[e] = p.bn_ss[n0 + ccol + e]; bn_sh[e] = p.bn_ss[p.N + n0 + ccol + e];
@@ -559,7 +562,6 @@ void igemm_kernel(IgemmArgs p) {
         MTN_UNROLL for (int i = 0; i < RPT; ++i) {
             const long m = orow[i] < 0 ? 0 : orow[i];
             bn_yv[i] = *reinterpret_cast<const chunk16*>(gBy + m * p.bn_ldy + n0 + ccol);
-            if (gBr) bn_rv[i] = *reinterpret_cast<const chunk16*>(gBr + m * p.bn_ldr + n0 + ccol);
         }
     }
     // The MFMAs take the W fragment as their row operand, so a lane's four accumulator registers
@@ -585,6 +587,10 @@ void igemm_kernel(IgemmArgs p) {
         if (p.act == MTN_ACT_GELU) {
             if (gAux) *reinterpret_cast<chunk16*>(gAux + (long)m * p.ld_aux + n0 + ccol) = pack<T>(v);
             MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = geluf_(v[e]);
+        } else if (MODE == 4) {                        // GELU backward on a data gradient: aux holds the saved pre-activation
+            float av[VEC];
+            unpack<T>(*reinterpret_cast<const chunk16*>(gAux + (long)m * p.ld_aux + n0 + ccol), av);
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] *= gelu_grad_(av[e]);
         }
         if (gR) {
             float rr[VEC];
@@ -599,7 +605,7 @@ void igemm_kernel(IgemmArgs p) {
             if (gBy) {          // sum dz, sum dz*xhat of the BatchNorm unit whose output gradient this row is
                 float yv[VEC], rr[VEC], dz[VEC], xh[VEC];
                 unpack<T>(bn_yv[i], yv);
-                if (gBr) unpack<T>(bn_rv[i], rr);
+                if (gBr) unpack<T>(*reinterpret_cast<const chunk16*>(gBr + (long)m * p.bn_ldr + n0 + ccol), rr);
                 bn_dz_math<VEC>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
                 MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
             } else {
@@ -696,6 +702,7 @@ static bool igemm_pointwise(const IgemmArgs& p) {
 // the default LDS-DMA double-buffer pipeline, specialised on the tap set
 template <class T, int BM, int BN, int WGM, int WGN>
 int launch_igemm_dma2(const IgemmArgs& p, hipStream_t stream) {
+    if (igemm_pointwise(p) && p.act == MTN_ACT_GELU_GRAD_) return launch_igemm<T, BM, BN, WGM, WGN, 3, 4>(p, stream);
     if (igemm_pointwise(p)) return launch_igemm<T, BM, BN, WGM, WGN, 3, 1>(p, stream);
     if (p.KH == 3 && p.KW == 3) return p.pm ? launch_igemm<T, BM, BN, WGM, WGN, 3, 3>(p, stream) : launch_igemm<T, BM, BN, WGM, WGN, 3, 2>(p, stream);
     return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
@@ -792,6 +799,8 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     }
     const int bk = dtype == MTN_BF16 ? 64 : 32;
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "igemm: bad dtype %d", dtype);
+    MTN_REQUIRE(p.act != MTN_ACT_GELU_GRAD_ || (igemm_pointwise(p) && g_igemm_stages == 5 && p.aux_out),
+                "igemm: the GELU-backward epilogue exists for 1x1 taps in the default pipeline only");
     MTN_REQUIRE(p.M > 0 && p.N > 0 && p.N % 64 == 0, "igemm: N=%d must be a positive multiple of 64 (M=%d)", p.N, p.M);
     MTN_REQUIRE(p.Cin % bk == 0, "igemm: Cin=%d must be a multiple of %d", p.Cin, bk);
     MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "igemm: K=%d != KH*KW*Cin", p.K);

@@ -5,6 +5,7 @@
 
 #define MTN_F32 MTN_DTYPE_F32
 #define MTN_BF16 MTN_DTYPE_BF16
+#define MTN_ACT_GELU_GRAD_ 100     // igemm epilogue only: multiply by gelu'(saved pre-activation)
 
 struct IgemmArgs {
     const void* A;        // NHWC activations, pixel stride lda (elements)
@@ -17,7 +18,7 @@ struct IgemmArgs {
     int mul, sgn, off, div;
     int M, N, K;
     const float* bias;    // [N] or null
-    int act;              // MTN_ACT_NONE / MTN_ACT_GELU
+    int act;              // MTN_ACT_NONE / MTN_ACT_GELU / MTN_ACT_GELU_GRAD_ (internal: out *= gelu'(aux), aux_out is READ)
     void* aux_out;        // pre-activation copy [M][ld_aux] (GELU backward) or null
     int ld_aux;
     const void* res;      // residual [M][ldr] added after act, or null (may alias Out)
@@ -88,6 +89,7 @@ int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res,
 int mtn_bn_bwd_blocks(int M);
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream);
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream);
+int mtn_colsum_ld_run(float* slab, int rows, int W, int ld, float* out, hipStream_t stream);
 
 int mtn_conv1_tiles(long M);
 int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int dtype, int B, int H, int W,

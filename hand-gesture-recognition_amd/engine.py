@@ -53,6 +53,7 @@ class Engine:
         self.on_grads_ready = None
         # data gradients pre-reduce the BatchNorm backward of the unit they feed (MTN_FUSE_BN_BWD=0: two-pass backward)
         self.fuse_bn_bwd = os.environ.get("MTN_FUSE_BN_BWD", "1") != "0"
+        self.fuse_gelu_bwd = os.environ.get("MTN_FUSE_GELU_BWD", "1") != "0"     # (0: three launches per FeedForward)
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -203,6 +204,9 @@ class Engine:
         self.t_qkv = self._new((Mt, 3 * D))
         self.delta = self._f32(B * self.heads, self.N)
         self.row_part = self._f32(ops.rowslab_rows(Mt), 2 * D)
+        mlp = self.layers[0]["fc1"].out_features
+        self.gelu_tiles = ops.linear_gelu_bwd_tiles(Mt, mlp, D)
+        self.gelu_part = self._f32(ops.slab_rows(self.gelu_tiles), 2, mlp)
         self.attn = self._f32(B, self.heads, self.N, self.N)
         self.logits = self._f32(B, self.C)
         self.hm = self._f32(B, self.J, 4 * self.fh, 4 * self.fw)
@@ -418,9 +422,13 @@ class Engine:
             # x2 = fc2(gelu(fc1(LN(x1)))) + x1
             ops.bias_grad(Gm, self.row_part, g(fc2.bias))
             ops.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
-            ops.linear_fwd(Gm, L["fc2_wd"], self.t_a)                       # d hgelu
-            ops.gelu_bwd(self.t_a, L["a"], self.t_b)                        # d a
-            ops.bias_grad(self.t_b, self.row_part, g(fc1.bias))
+            if self.fuse_gelu_bwd:
+                # d a = (G @ fc2.W) * gelu'(a) and fc1's bias gradient (its column sums) in one launch
+                ops.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, self.gelu_part, self.gelu_tiles, g(fc1.bias))
+            else:
+                ops.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
+                ops.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
+                ops.bias_grad(self.t_b, self.row_part, g(fc1.bias))
             ops.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
             ops.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
             ops.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, self.row_part,

@@ -101,6 +101,25 @@ def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None):
              dtype_code(x), M, N, K, _stream(x))
 
 
+def linear_gelu_bwd_tiles(M, N, K):
+    return lib.call("mtn_linear_gelu_bwd_tiles", M, N, K)
+
+
+def linear_gelu_bwd(dh, wt, a, da, partial, tiles, dbias):
+    """da = (dh @ wt.T) * gelu'(a); dbias = column sums of da (f32 [N], overwritten).  dh [M,K], wt [N,K], a / da [M,N]."""
+    K, N = dh.shape[-1], da.shape[-1]
+    M = dh.numel() // K
+    if a.shape != da.shape or a.dtype != da.dtype or dh.dtype != da.dtype:
+        raise ValueError("linear_gelu_bwd: a and da must have one shape and dtype")
+    if partial.dtype != torch.float32 or partial.numel() < slab_rows(tiles) * 2 * N or dbias.numel() != N or dbias.dtype != torch.float32:
+        raise ValueError("linear_gelu_bwd: partial slab / dbias size")
+    hp, ldh = _rows(dh)
+    ap, lda = _rows(a)
+    dp, ldd = _rows(da)
+    lib.call("mtn_linear_gelu_bwd", hp, ldh, wt.data_ptr(), ap, lda, dp, ldd, partial.data_ptr(), tiles, dbias.data_ptr(),
+             dtype_code(dh), M, N, K, _stream(dh))
+
+
 def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride):
     return lib.call("mtn_conv_wgrad_workspace_bytes", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
 

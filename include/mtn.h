@@ -171,6 +171,15 @@ int mtn_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const fl
                       float* partial, float* dgamma_dbeta, int dtype, int M, void* stream);
 /* da = dh * gelu'(a), exact erf GELU (transformer.py:35); n elements, contiguous */
 int mtn_gelu_bwd(const void* dh, const void* a, void* da, int dtype, long long n, void* stream);
+/* The backward of `Linear -> GELU -> Linear` (FeedForward, transformer.py:34-37) around the GELU in one
+ * launch: da = (dh @ wt^T) * gelu'(a) -- the data gradient of the second Linear (wt = its weight packed
+ * [N][K], dh [M][K]) with the GELU backward applied in its epilogue -- and dbias[N] = column sums of da
+ * as stored (the bias gradient of the first Linear).  Replaces mtn_linear_fwd + mtn_gelu_bwd +
+ * mtn_bias_grad.  partial: f32 [mtn_slab_rows(tiles)][2][N], tiles = mtn_linear_gelu_bwd_tiles(M, N, K). */
+int mtn_linear_gelu_bwd_tiles(int M, int N, int K);
+int mtn_linear_gelu_bwd(const void* dh, int lddh, const void* wt, const void* a, int lda, void* da,
+                        int ldda, float* partial, int tiles, float* dbias, int dtype, int M, int N,
+                        int K, void* stream);
 /* dbias[256] = column sums of dy[M][256] */
 int mtn_bias_grad(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, void* stream);
 

@@ -76,6 +76,31 @@ def test_gelu_bwd_and_bias_grad(be, dtype):
     assert rel_err(db, dh.float().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(70, 256, 256), (300, 128, 256), (40000, 256, 256)])
+def test_linear_gelu_bwd(be, dtype, cfg):
+    """da = (dh @ wt.T) * gelu'(a) and dbias = column sums of da, against the three separate steps."""
+    M, N, K = cfg
+    if be.name == "emu" and M > 1000:
+        pytest.skip("large case (several hundred slab rows, folded twice) is for the GPU")
+    d = be.device
+    dh, a = _rand((M, K), dtype, 20), _rand((M, N), dtype, 21)
+    wt = (_rand((N, K), torch.float32, 22) / K ** 0.5).to(dtype)
+    ar = a.float().requires_grad_(True)
+    F.gelu(ar).backward(torch.ones_like(ar))
+    pre = dh.float() @ wt.float().t()
+    ref = pre * ar.grad
+    da = torch.full((M, N), float("nan"), dtype=dtype, device=d)
+    tiles = ops.linear_gelu_bwd_tiles(M, N, K)
+    part = torch.full((ops.slab_rows(tiles), 2, N), float("nan"), device=d)
+    wide = torch.full((3 * N,), 7.0, device=d)          # the bias gradient is a slice of the flat gradient buffer
+    ops.linear_gelu_bwd(dh.to(d), wt.to(d), a.to(d), da, part, tiles, wide[N:2 * N])
+    be.sync()
+    assert rel_err(da.float(), ref) < tol(dtype, 1e-5, 1e-2)
+    assert rel_err(wide[N:2 * N], da.float().sum(0)) < 1e-5 or float((wide[N:2 * N] - da.float().sum(0)).abs().max()) < 1e-3
+    assert float((wide[:N] - 7).abs().max()) == 0 and float((wide[2 * N:] - 7).abs().max()) == 0
+
+
 def _attn_ref(qkv, B, N, H, D):
     q, k, v = (t.reshape(B, N, H, D).permute(0, 2, 1, 3) for t in qkv.reshape(B, N, 3 * H * D).chunk(3, -1))
     attn = torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1)
