@@ -29,19 +29,31 @@ int mtn_abi_version(void) { return 3; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
-int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int stats_tiles, int dtype,
-                 int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
-    MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_fwd: ksize=%d", ksize);
-    MTN_REQUIRE(stride == 1 || stride == 2, "conv_fwd: stride=%d", stride);
+static int conv_fwd_args(IgemmArgs& p, const char* who, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    MTN_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize=%d", who, ksize);
+    MTN_REQUIRE(stride == 1 || stride == 2, "%s: stride=%d", who, stride);
     const int pad = ksize / 2;
-    IgemmArgs p{};
-    p.A = x; p.Wp = w; p.Out = y; p.lda = ldx; p.ldc = ldy;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin;
     p.OH = (H + 2 * pad - ksize) / stride + 1;
     p.OW = (W + 2 * pad - ksize) / stride + 1;
     p.KH = p.KW = ksize;
     p.mul = stride; p.sgn = 1; p.off = -pad; p.div = 1;
     p.M = B * p.OH * p.OW; p.N = Cout; p.K = ksize * ksize * Cin;
+    return MTN_OK;
+}
+
+int mtn_conv_fwd_stats_tiles(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    IgemmArgs p{};
+    if (conv_fwd_args(p, "conv_fwd_stats_tiles", B, H, W, Cin, Cout, ksize, stride)) return -1;
+    return mtn_igemm_stats_tiles(p, dtype);
+}
+
+int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int stats_tiles, int dtype,
+                 int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+    IgemmArgs p{};
+    const int rc = conv_fwd_args(p, "conv_fwd", B, H, W, Cin, Cout, ksize, stride);
+    if (rc) return rc;
+    p.A = x; p.Wp = w; p.Out = y; p.lda = ldx; p.ldc = ldy;
     p.stats = stats;
     p.stats_rows = stats_tiles;
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
@@ -345,6 +357,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 13) { mtn_wgrad_set_win(value); return MTN_OK; }
     if (key == 14) { mtn_pose_set_row(value); return MTN_OK; }
     if (key == 15) { mtn_dgrad2_set(value); return MTN_OK; }
+    if (key == 16) { mtn_igemm_set_image_tiles(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

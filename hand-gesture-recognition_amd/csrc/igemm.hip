@@ -89,11 +89,13 @@ void igemm_kernel(IgemmArgs p) {
     constexpr int RSTEP = NT / 8;        // rows between a thread's chunks
     typedef typename std::conditional<STAGES != 2, T, float>::type CT;     // staged C element
     constexpr bool DMA = STAGES >= 3;
-    constexpr bool WIN = STAGES == 5;
+    constexpr bool WIN = STAGES == 5 || STAGES == 6;
+    constexpr bool IMG = STAGES == 6;      // window mode, whole reduction axis resident, weights through registers
+    constexpr int WOFF = IMG ? 0 : 2 * BN; // LDS rows in front of the window (the two W tiles)
     constexpr int NBUF = STAGES == 1 ? 1 : (STAGES == 4 ? 3 : 2);
     constexpr int PITCH_E = DMA ? BK : PITCH;                              // LDS row pitch in elements
     constexpr int CP = BN + 16 / (int)sizeof(CT);                          // pitch of the staged C tile
-    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "loader mapping");
+    static_assert((STAGES >= 5 || BM * 8 % NT == 0) && BN * 8 % NT == 0, "loader mapping");
 
     MTN_DYN_SMEM(smem);
     // MODE fixes the tap set at compile time (0: runtime): 1 = 1x1 taps at stride 1 in natural row
@@ -112,8 +114,8 @@ void igemm_kernel(IgemmArgs p) {
     // number of passes over Cin, and the LDS regions [CS][WR8][BK] window + one zero row
     const int win_halo = WIN ? p.W + 1 : 0;
     const int WR8 = (BM + 2 * win_halo + 7) & ~7;
-    const int CS = p.Cin / BK >= 2 ? 2 : 1;
-    T* const sWin = sB + 2 * BN * BK;
+    const int CS = WIN ? p.win_cs : 1;
+    T* const sWin = sB + WOFF * BK;
     T* const sZero = sWin + CS * WR8 * BK;
     CT* const sC = reinterpret_cast<CT*>(smem);                     // [BM][CP] (after the K loop)
 
@@ -394,7 +396,7 @@ void igemm_kernel(IgemmArgs p) {
         MTN_UNROLL for (int i = 0; i < FM; ++i) {
             const int j = wm * WM + i * 16 + frow + delta;
             const bool ok = ((f_vy[i] >> kh) & (f_vx[i] >> kw)) & 1u;
-            aoff[i] = ok ? (2 * BN + cs * WR8 + j) * BK : (2 * BN + CS * WR8) * BK;
+            aoff[i] = ok ? (WOFF + cs * WR8 + j) * BK : (WOFF + CS * WR8) * BK;
             asw[i] = j & 7;
         }
         mma_step([&](int ks, int i) { const int e = ks * KI + fk; return Mma<T>::load(sB + aoff[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC)); },
@@ -426,7 +428,47 @@ void igemm_kernel(IgemmArgs p) {
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
 #endif
-    if (WIN) {
+    if constexpr (IMG) {
+        // STAGES = 6: the window holds ALL Cin channels of the tile's rows, loaded once; a wave's weight
+        // fragments (its own WN columns) come straight from global memory into registers, D K-steps ahead (the
+        // compiler counts vmcnt for register loads), and the K loop has NO barrier and no LDS writes -- the
+        // waves of the workgroup drift apart and overlap each other's load and MFMA phases, which a workgroup
+        // that meets at a barrier every K step cannot.
+        constexpr int D = 3, KS = BK / KI;
+        dma_window(0);
+        __syncthreads();
+        const int steps = 9 * CS;                          // CS in {1, 2, 4}: a multiple of D... 9, 18, 36
+        const int cs_shift = CS == 4 ? 2 : (CS == 2 ? 1 : 0);
+        typename Mma<T>::Frag wq[D][KS][FN];
+        auto load_w = [&](int kk, int slot) {
+            const int tap = kk >> cs_shift, cs = kk - (tap << cs_shift);
+            const T* w = gW + (long)(n0 + wn * WN + frow) * p.K + tap * p.Cin + cs * BK + fk;
+            MTN_UNROLL for (int ks = 0; ks < KS; ++ks)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) wq[slot][ks][j] = Mma<T>::load(w + (long)j * 16 * p.K + ks * KI);
+        };
+        auto compute_img = [&](int kk, int slot) {
+            const int tap = kk >> cs_shift, cs = kk - (tap << cs_shift);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int delta = (kh * p.sgn + p.off) * p.W + (kw * p.sgn + p.off) + win_halo;
+            int aoff[FM], asw[FM];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) {
+                const int j = wm * WM + i * 16 + frow + delta;
+                const bool ok = ((f_vy[i] >> kh) & (f_vx[i] >> kw)) & 1u;
+                aoff[i] = ok ? (cs * WR8 + j) * BK : CS * WR8 * BK;
+                asw[i] = j & 7;
+            }
+            mma_step([&](int ks, int i) { const int e = ks * KI + fk; return Mma<T>::load(sWin + aoff[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC)); },
+                     [&](int ks, int j) { return wq[slot][ks][j]; });
+        };
+        MTN_UNROLL for (int d = 0; d + 1 < D; ++d) load_w(d, d);
+        for (int kk = 0; kk < steps; kk += D) {
+            MTN_UNROLL for (int d = 0; d < D; ++d) {
+                if (kk + d + D - 1 < steps) load_w(kk + d + D - 1, (d + D - 1) % D);
+                compute_img(kk + d, d);
+            }
+        }
+        __syncthreads();                                   // every wave is done with the window: the C tile takes its place
+    } else if (WIN) {
         const int slabs = p.Cin / (CS * BK), steps = 9 * CS;
         for (int slab = 0; slab < slabs; ++slab) {
             __syncthreads();                               // the previous window / W tiles are consumed
@@ -643,23 +685,44 @@ void igemm_kernel(IgemmArgs p) {
 }
 
 // LDS bytes of the window mode: two W tiles + the window rows of the resident channel slabs + a zero row
-static size_t igemm_window_bytes(const IgemmArgs& p, int bm, int bn, int esz) {
-    const int bk = ROW_BYTES / esz;
-    const int cs = p.Cin / bk >= 2 ? 2 : 1;
+static size_t igemm_window_bytes(const IgemmArgs& p, int bm, int bn, int cs) {      // bn = 0: no W tiles in LDS (STAGES = 6)
     const size_t wr8 = (size_t)((bm + 2 * (p.W + 1) + 7) & ~7);
     return (2 * (size_t)bn + cs * wr8 + 1) * ROW_BYTES;
+}
+static int igemm_window_cs(const IgemmArgs& p, int esz) { return p.Cin / (ROW_BYTES / esz) >= 2 ? 2 : 1; }
+static bool igemm_window_shape(const IgemmArgs& p) {
+    return p.KH == 3 && p.KW == 3 && p.mul == 1 && p.div == 1 && !p.pm && p.OH == p.H && p.OW == p.W;
 }
 
 // window mode serves stride-1 3x3 taps whose LDS footprint still lets three workgroups share a CU
 // (53 KB): measured per layer it wins 25 % there (64-channel stage-1
 // layers) and loses to the plain LDS-DMA pipeline once the window costs a resident workgroup.
 // Debug key 9 raises the limit (tests run every shape through the window path).
+static int g_tile_n64 = 128;     // rows per tile for 64-wide outputs (debug key 4)
+static int g_igemm_stages = 5;   // window mode where it pays, LDS-DMA double buffer elsewhere (DESIGN.md section 4)
 static int g_window_limit_kb = 53;
 static bool igemm_window_ok(const IgemmArgs& p, int bm, int bn, int esz) {
     const int bk = ROW_BYTES / esz;
-    const int cs = p.Cin / bk >= 2 ? 2 : 1;
-    return p.KH == 3 && p.KW == 3 && p.mul == 1 && p.div == 1 && !p.pm && p.OH == p.H && p.OW == p.W &&
-           p.Cin % (cs * bk) == 0 && igemm_window_bytes(p, bm, bn, esz) <= (size_t)g_window_limit_kb * 1024;
+    const int cs = igemm_window_cs(p, esz);
+    return igemm_window_shape(p) && p.Cin % (cs * bk) == 0 && igemm_window_bytes(p, bm, bn, cs) <= (size_t)g_window_limit_kb * 1024;
+}
+
+// "Image tiles": window mode with the WHOLE reduction axis resident -- a 144-row x 256-column tile (one 12x12
+// image of the stage-3 maps per workgroup, 8 waves side by side over the columns, one workgroup per CU) keeps
+// its 144 + 2(W+1) window rows of all Cin <= 256 channels in LDS (<= 90 KB) beside two 256 x 128-byte weight
+// tiles: the activations cross L2 -> LDS once per tile instead of once per tap and column tile, and only
+// weights stream (2.25x the FLOPs per byte through the DMA path of the 128x128 double buffer).
+static int g_image_tiles = 1;      // debug key 16: 0 = off, 1 = on, 3 = on and ignore the tile-count floor (tests)
+constexpr int IMG_BM = 144, IMG_BN = 256;
+// (Measured and dropped: 288 x 128 with waves 2 x 4 for the 24 x 24 stage-2 maps, +10 % slower than the 128 x 128
+//  double buffer; 256 x 64 with waves 4 x 2 for stage 1, +25 % slower than the 53 KB window mode -- DESIGN.md 7c.)
+static bool igemm_image_tile_ok(const IgemmArgs& p, int esz) {
+    if (!g_image_tiles || g_igemm_stages != 5 || esz != 2 || !igemm_window_shape(p) || p.N % IMG_BN) return false;
+    const int bk = ROW_BYTES / esz, cs = p.Cin / bk;
+    if ((cs != 1 && cs != 2 && cs != 4) || p.Cin % bk) return false;
+    if (igemm_window_bytes(p, IMG_BM, 0, cs) > 158 * 1024) return false;
+    const long tiles = (long)mtn_cdiv(p.M, IMG_BM) * (p.N / IMG_BN);
+    return tiles >= 192 || (g_image_tiles & 2);     // one workgroup per CU: fewer tiles leave CUs idle
 }
 
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
@@ -671,28 +734,29 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
     constexpr size_t lds0 = lds_ab > lds_c ? lds_ab : lds_c;
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
-    if (STAGES == 5) {
-        const size_t win = igemm_window_bytes(p, BM, BN, (int)sizeof(T));
+    int win_cs = 0;
+    if (STAGES >= 5) {
+        win_cs = STAGES == 6 ? p.Cin / (ROW_BYTES / (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T));
+        const size_t win = igemm_window_bytes(p, BM, STAGES == 6 ? 0 : BN, win_cs);
         const size_t rest = lds_c > lds_r ? lds_c : lds_r;
         lds = win > rest ? win : rest;
     }
 #ifndef MTN_EMU
     static MtnLdsAttr attr;
-    mtn_set_max_lds(attr, &igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>, STAGES == 5 ? 160 * 1024 : lds);
+    mtn_set_max_lds(attr, &igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>, STAGES >= 5 ? 160 * 1024 : lds);
 #endif
     const int tiles = mtn_cdiv(p.M, BM) * (p.N / BN);
     MTN_REQUIRE(!p.stats || p.stats_rows == mtn_cdiv(p.M, BM),
                 "igemm: the statistics slab was sized for %d row tiles, this launch writes %d (tile choice changed after "
                 "mtn_conv_stats_tiles was queried?)", p.stats_rows, mtn_cdiv(p.M, BM));
     IgemmArgs q = p;
+    q.win_cs = win_cs;
     q.magic_tn = p.N / BN > 1 ? (unsigned)(0x100000000ull / (unsigned)(p.N / BN)) + 1u : 0u;
     MTN_REQUIRE((long)tiles * (p.N / BN) < (1L << 32), "igemm: too many tiles");
     MTN_LAUNCH((igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>), dim3(tiles), dim3(NT), lds, stream, q);
     return mtn_check_launch("igemm");
 }
 
-static int g_tile_n64 = 128;     // rows per tile for 64-wide outputs (debug key 4)
-static int g_igemm_stages = 5;   // window mode where it pays, LDS-DMA double buffer elsewhere (DESIGN.md section 4)
 
 // 1x1 taps at stride 1 in natural row order: every 1x1 convolution (forward and data gradient) and Linear
 static bool igemm_pointwise(const IgemmArgs& p) {
@@ -746,6 +810,9 @@ static int igemm_config(int M, int N, int K) {
 
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2) {
+        if (igemm_image_tile_ok(p, 2)) return launch_igemm<T, IMG_BM, IMG_BN, 1, 8, 6, 2>(p, stream);
+    }
     const int cfg = igemm_config(p.M, p.N, p.K);
     // 128x128 runs with 8 waves (4x2, 32x64 per wave) in the default pipelines: an LDS-DMA
     // instruction costs its wave ~100 cycles of issue, so 4 pieces per wave instead of 8 shorten the
@@ -761,6 +828,8 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
 
 void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 5) ? n : 5; }
 void mtn_igemm_set_window_limit(int kb) { g_window_limit_kb = (kb > 0 && kb <= 150) ? kb : 53; }
+
+void mtn_igemm_set_image_tiles(int v) { g_image_tiles = v & 3; }
 
 void mtn_igemm_set_tile_n64(int rows) { g_tile_n64 = rows == 256 ? 256 : 128; }
 
@@ -783,6 +852,7 @@ int mtn_igemm_tiles_m(int M, int N, int K) {
 
 int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_tiles_m(p);
+    if (igemm_image_tile_ok(p, dtype == MTN_BF16 ? 2 : 4)) return mtn_cdiv(p.M, IMG_BM);
     return mtn_igemm_tiles_m(p.M, p.N, p.K);
 }
 

@@ -34,6 +34,7 @@ struct IgemmArgs {
     const float* bn_mr;   // [2][N] mean, rstd
     int bn_act;
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
+    int win_cs;           // filled at launch (window mode): resident 128-byte channel slabs of the activation window
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
     unsigned magic_tn;           // filled at launch: multiply-high divisor of the tile index (N / BN)
     unsigned a_bytes, w_bytes;   // filled by mtn_igemm_run: byte extents of A / Wp (buffer descriptors)
@@ -162,6 +163,7 @@ void mtn_wgrad_set_dma(int on);
 void mtn_igemm_set_tile(int t);
 void mtn_igemm_set_dbg(int v);
 void mtn_igemm_set_window_limit(int kb);
+void mtn_igemm_set_image_tiles(int on);
 int mtn_igemm_read_stamps(void* dst, size_t bytes);
 void mtn_wgrad_set_tile(int t);
 void mtn_wgrad_set_slots(int n);

@@ -147,7 +147,7 @@ class Engine:
             # recomputed from the image instead of stored
             u.raw = self._new((B, u.hout, u.wout, u.cout)) if u is not self.u_conv1 else None
             if u.bn:
-                tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_stats_tiles(M, u.cout, u.k * u.k * u.cin)
+                tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_fwd_stats_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
                 u.tiles = tiles
                 u.stats = self._f32(ops.slab_rows(tiles), 2, u.cout)
                 u.ss, u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout), self._f32(2, u.cout)

@@ -20,6 +20,7 @@ _PROTOS = {
     "mtn_conv_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_dgrad_bn_tiles": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "mtn_conv_fwd_stats_tiles": [_i, _i, _i, _i, _i, _i, _i, _i],
     "mtn_conv_dgrad_bn": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
                           _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_linear_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
@@ -72,7 +73,7 @@ _PROTOS = {
     "mtn_debug_read": [_i, _vp, _sz],
 }
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}
-_STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
+_STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
                 "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",

@@ -41,9 +41,14 @@ def conv_stats_tiles(M, cout, K):
     return lib.call("mtn_conv_stats_tiles", M, cout, K)
 
 
+def conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
+    """rows of the partial-statistics slab conv_fwd writes for this layer geometry."""
+    return lib.call("mtn_conv_fwd_stats_tiles", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
+
+
 def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
     """x [B,H,W,Cin] -> y [B,OH,OW,Cout] raw conv output; stats [>=tiles,2,Cout] f32 or None
-    (tiles = conv_stats_tiles(M, Cout, K): the slab is allocated with slab_rows(tiles) rows)."""
+    (tiles = conv_fwd_stats_tiles(...): the slab is allocated with slab_rows(tiles) rows)."""
     B, H, W, Cin = x.shape
     Cout = y.shape[-1]
     xp, ldx = _rows(x)
@@ -52,7 +57,7 @@ def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
     if stats is not None:
         # the row count the slab was SIZED for (a plan passes what it allocated; the library refuses
         # the launch if its tile choice no longer matches)
-        tiles = conv_stats_tiles(y.numel() // Cout, Cout, ksize * ksize * Cin) if stats_tiles is None else int(stats_tiles)
+        tiles = conv_fwd_stats_tiles(x.dtype, B, H, W, Cin, Cout, ksize, stride) if stats_tiles is None else int(stats_tiles)
         if stats.dtype != torch.float32 or stats.numel() < tiles * 2 * Cout:
             raise ValueError(f"conv_fwd: stats slab too small for {tiles} row tiles")
     lib.call("mtn_conv_fwd", xp, ldx, w.data_ptr(), yp, ldy, _p(stats), tiles, dtype_code(x),

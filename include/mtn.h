@@ -39,13 +39,15 @@ int mtn_abi_version(void);
 
 /* ---- GELAN backbone: Conv2d(bias=False) -> BatchNorm2d(train) -> SiLU  (model/gelan.py:37-56) */
 
-/* number of row tiles whose partial BN statistics mtn_conv_fwd writes: stats is [tiles][2][Cout].
- * M = B*OH*OW output pixels, K = ksize*ksize*Cin (the tile shape is chosen per layer). */
+/* number of row tiles whose partial BN statistics mtn_conv_fwd writes: stats is [tiles][2][Cout]
+ * (the tile shape is chosen per layer from its whole geometry).  mtn_conv_stats_tiles(M, Cout, K) is
+ * the geometry-free form for 1x1 convolutions / Linear-shaped calls (M = B*OH*OW, K = Cin). */
+int mtn_conv_fwd_stats_tiles(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 int mtn_conv_stats_tiles(int M, int Cout, int K);
 
 /* y_raw = conv(x) (k in {1,3}, pad k/2, stride in {1,2}); w packed [Cout][k][k][Cin];
  * stats (optional) receives per-tile per-channel sum / sum-of-squares of y_raw; stats_tiles is the
- * row count the caller sized it for and must equal mtn_conv_stats_tiles(M, Cout, K) (checked:
+ * row count the caller sized it for and must equal mtn_conv_fwd_stats_tiles(...) (checked:
  * the kernel writes exactly that many rows and mtn_bn_finalize reads them). */
 int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int stats_tiles,
                  int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,

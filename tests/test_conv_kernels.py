@@ -65,6 +65,56 @@ def test_conv_fwd_and_stats(be, stages, dtype, cfg):
     assert rel_err(st[1], (yf * yf).sum(0)) < 1e-4
 
 
+@pytest.fixture
+def image_tiles(be):
+    """force the image tiles (whole reduction axis resident in LDS) on shapes the CPU executor can run"""
+    from hand_gesture_recognition_amd import lib
+    lib.call("mtn_debug_set", 16, 3)
+    yield
+    lib.call("mtn_debug_set", 16, 1)
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout   (3x3 stride 1, bf16 only: Cin / 64 in {1, 2, 4} resident slabs)
+    (2, 12, 12, 64, 256),        # two tiles = two images
+    (3, 5, 7, 128, 256),         # one partial tile, three images inside it
+    (1, 13, 12, 256, 512),       # four resident slabs, two column tiles, a ragged second row tile
+])
+def test_conv_image_tiles(be, image_tiles, cfg):
+    """igemm_kernel<144, 256, 1, 8, window>: forward with statistics, data gradient with residual and
+    BatchNorm-backward sums, against torch."""
+    dtype = torch.bfloat16
+    B, H, W, Cin, Cout = cfg
+    d = be.device
+    x = _rand((B, H, W, Cin), dtype, 71)
+    w = _rand((Cout, Cin, 3, 3), torch.float32, 72) / (Cin * 9) ** 0.5
+    wq = w.to(dtype).float()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wq, None, 1, 1).permute(0, 2, 3, 1)
+    M = B * H * W
+    tiles = ops.conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, 3, 1)
+    assert tiles == (M + 143) // 144
+    y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=d)
+    stats = torch.full((tiles, 2, Cout), float("nan"), device=d)
+    ops.conv_fwd(x.to(d), pack_krsc(w, dtype).to(d), y, stats, 3, 1)
+    be.sync()
+    assert rel_err(y.float(), ref) < tol(dtype)
+    yf = y.float().cpu().reshape(M, Cout)
+    assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3 and rel_err(stats.cpu().sum(0)[1], (yf * yf).sum(0)) < 1e-3
+    # data gradient of a Cout -> Cin... here the transposed roles: dy has Cout2 = Cin channels in, dx 256-wide out
+    if Cout == 256:
+        w2 = _rand((Cin, Cout, 3, 3), torch.float32, 73) / (Cin * 9) ** 0.5         # conv Cout -> Cin; its dgrad: N = Cout, K = 9 Cin
+        xz = torch.zeros((B, Cout, H, W), requires_grad=True)
+        yr = F.conv2d(xz, w2.to(dtype).float(), None, 1, 1)
+        dy = _rand((B, H, W, Cin), dtype, 74)
+        res = _rand((B, H, W, Cout), dtype, 75)
+        yr.backward(dy.float().permute(0, 3, 1, 2))
+        dref = xz.grad.permute(0, 2, 3, 1) + res.float()
+        dx = res.clone().to(d)
+        ops.conv_dgrad(dy.to(d), pack_crsk(w2, dtype).to(d), dx, dx, 3, 1)
+        be.sync()
+        assert rel_err(dx.float(), dref) < tol(dtype)
+
+
 def test_conv_fwd_refuses_a_stats_slab_sized_for_another_tile(be):
     """A debug key that changes the tile after the plan sized its slab must fail the launch, not
     write a different number of statistics rows than bn_finalize will read."""

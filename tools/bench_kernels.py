@@ -109,7 +109,7 @@ def main():
         w = (torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(dt)
         y = torch.empty(B, OH, OW, Cout, device=dev, dtype=dt)
         M = B * OH * OW
-        stats = torch.empty(ops.conv_stats_tiles(M, Cout, k * k * Cin), 2, Cout, device=dev)
+        stats = torch.empty(ops.conv_fwd_stats_tiles(dt, B, H, W, Cin, Cout, k, s), 2, Cout, device=dev)
         t = timeit(lambda: ops.conv_fwd(x, w, y, stats, k, s))
         fl = 2.0 * M * Cout * k * k * Cin
         by = (x.numel() + y.numel() + w.numel()) * esz
