@@ -69,9 +69,12 @@ def igemm_roofline(step, batch):
         Cin, Cout, M = x.shape[-1], y.shape[-1], y.numel() // y.shape[-1]
         return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y), k
 
-    def g_dgrad(dy, wt, dx, res, k, s):
+    def g_dgrad(dy, wt, dx, res, k, s, bn=None):
         Cout, Cin, Mout = dy.shape[-1], dx.shape[-1], dy.numel() // dy.shape[-1]
-        return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res), k
+        # (a launch that also writes the BatchNorm-backward sums of the next unit reads that unit's raw output too)
+        extra = (bn[0], bn[1]) if bn is not None else ()
+        # 3x3 stride-2 data gradients run dgrad2_kernel, not the igemm template: their own family below
+        return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res, *extra), (32 if (k == 3 and s == 2) else k)
 
     def g_lin(x, w, out, bias=None, act=0, aux_out=None, res=None):
         K, N = x.shape[-1], out.shape[-1]
@@ -86,9 +89,12 @@ def igemm_roofline(step, batch):
         torch.cuda.synchronize()
     finally:
         ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = saved
+    all_times = [r[2].elapsed_time(r[3]) * 1e-3 for r in rec]
+    d2 = [(r, t) for r, t in zip(rec, all_times) if r[1][2] == 32]
+    keep = [(r, t) for r, t in zip(rec, all_times) if r[1][2] != 32]
+    rec, times = [r for r, _ in keep], [t for _, t in keep]
     flops = sum(r[1][0] for r in rec)
     abytes = sum(r[1][1] for r in rec)
-    times = [r[2].elapsed_time(r[3]) * 1e-3 for r in rec]
     secs = sum(times)
     achieved = flops / secs / 1e12
     # the template's two regimes, reported separately as well: 3x3 convolutions (forward and data gradient;
@@ -106,6 +112,12 @@ def igemm_roofline(step, batch):
                       "unit": "GB/s", "frac": round(fam["pointwise"][1] / fam["pointwise"][2] / 1e9 / HBM_PEAK_GBS, 4),
                       "launches_per_step": fam["pointwise"][3], "share_of_step_ms": round(fam["pointwise"][2] * 1e3, 3)},
     }
+    if d2:
+        f2, b2, t2 = sum(r[1][0] for r, _ in d2), sum(r[1][1] for r, _ in d2), sum(t for _, t in d2)
+        families["conv3x3_stride2_dgrad"] = {"kernel": "dgrad2_kernel", "bound": "hbm", "achieved": round(b2 / t2 / 1e9, 1),
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b2 / t2 / 1e9 / HBM_PEAK_GBS, 4),
+                                             "tflops": round(f2 / t2 / 1e12, 1), "launches_per_step": len(d2),
+                                             "share_of_step_ms": round(t2 * 1e3, 3)}
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes),
     # averaged over all instances of the template
@@ -121,7 +133,8 @@ def igemm_roofline(step, batch):
         if n:
             traffic, src = round(tot / n), "profiles/" + name
         break
-    return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,...> (all instances: conv fwd + conv dgrad + ViT linears, one launch per call)",
+    return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,...> (all instances: conv fwd + conv dgrad + ViT linears, one launch per call; not counted: "
+                      "the 4 fc2 data gradients fused with GELU' / bias sums, whose call brackets three launches)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
