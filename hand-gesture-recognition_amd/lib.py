@@ -96,6 +96,12 @@ def _bind(path):
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _i)
+    # diagnostics: MTN_DEBUG_KEYS="16=0,15=0" applies mtn_debug_set(key, value) to every process that loads the library
+    # (A/B runs of tools that have no --key option); unset in normal use
+    for kv in filter(None, os.environ.get("MTN_DEBUG_KEYS", "").split(",")):
+        k, v = kv.split("=")
+        if lib.mtn_debug_set(int(k), int(v)):
+            raise RuntimeError(f"MTN_DEBUG_KEYS: {lib.mtn_last_error().decode()}")
     return lib
 
 
