@@ -352,6 +352,10 @@ class Engine:
     # ---------------------------------------------------------------- backward
     def backbone_backward(self, g_feats):
         """Backward of backbone_forward given the gradient of its NHWC output (written into g buffers)."""
+        for st in self.stages:          # (entered directly: no hand-over can be pending for the backbone's units except the
+            for u in (st["cv1"], st["down"]):                          # last cv4, which the projection's data gradient feeds)
+                if u is not None:
+                    u.pre_rows = 0
         g_cur = g_feats
         for st in reversed(self.stages):
             C, cat, gc = st["C"], st["cat"], st["g_cat"]
