@@ -1,0 +1,56 @@
+"""Loss trajectories of the same training run on three engines: the CPU oracle (fp32, PyTorch-CPU restatement of the
+reference), the HIP path in fp32 validation mode and in bf16 throughput mode.  Same synthetic weights, the same four
+synthetic batches cycled, AdamW lr 1e-3, train-mode BatchNorm.  Not a parity gate (those are in tests/): a check that the
+throughput mode TRAINS like the reference arithmetic over many steps, not only for one.
+usage (GPU box): python tools/convergence_check.py [--steps 120] [--batch 16] [--size 192]"""
+import argparse, os, sys, time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mtn_oracle as O  # noqa: E402
+from hand_gesture_recognition_amd.multitasknet import MultiTaskNet  # noqa: E402
+from hand_gesture_recognition_amd.train import TrainStep  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=120)
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--size", type=int, default=192)
+ap.add_argument("--lr", type=float, default=1e-3)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+batches = [O.synthetic_batch(a.batch, a.size, seed=100 + i) for i in range(4)]
+
+curves = {}
+t0 = time.time()
+sd = O.synthetic_state_dict(21, 19, seed=7)
+st = {}
+curves["oracle fp32 (CPU)"] = []
+for i in range(a.steps):
+    _, losses, _ = O.train_step(sd, batches[i % 4], st, a.lr)
+    curves["oracle fp32 (CPU)"].append([float(x) for x in losses])
+t_cpu = time.time() - t0
+for name, dt in (("HIP fp32", torch.float32), ("HIP bf16", torch.bfloat16)):
+    model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=dt)
+    model.load_state_dict(O.synthetic_state_dict(21, 19, seed=7), strict=True)
+    model.to(dev).train()
+    step = TrainStep(model, a.batch, lr=a.lr)
+    dbs = [tuple(t.to(dev) for t in b) for b in batches]
+    curves[name] = []
+    for i in range(a.steps):
+        curves[name].append([float(x) for x in step(*dbs[i % 4]).cpu()])
+
+ref = curves["oracle fp32 (CPU)"]
+print(f"# {a.steps} AdamW steps (lr {a.lr}), B={a.batch}, {a.size}x{a.size}, 4 synthetic batches cycled; oracle on {torch.get_num_threads()} CPU threads: {t_cpu:.0f} s")
+print(f"{'step':>5s} " + " ".join(f"{k:>22s}" for k in curves) + "    (total loss = 0.001*CE + JointsMSE)")
+for i in sorted(set(list(range(0, a.steps, max(1, a.steps // 12))) + [a.steps - 1])):
+    print(f"{i:5d} " + " ".join(f"{curves[k][i][0]:22.6f}" for k in curves))
+for k in curves:
+    if k == "oracle fp32 (CPU)":
+        continue
+    dev_rel = max(abs(c[0] - r[0]) / abs(r[0]) for c, r in zip(curves[k], ref))
+    print(f"# {k}: max relative deviation of the total loss from the oracle over the run {dev_rel:.3e}; "
+          f"final {curves[k][-1][0]:.6f} vs {ref[-1][0]:.6f} (start {ref[0][0]:.6f})")
