@@ -148,7 +148,10 @@ static int conv_wgrad_args(WgradArgs& p, int dtype, int B, int H, int W, int Cin
     if (Cout % 64 != 0 || Cin % 64 != 0) { mtn_set_error("wgrad: Cout=%d, Cin=%d must be multiples of 64", Cout, Cin); return 1; }
     p.win = mtn_wgrad3_ok(dtype, H, W, ksize, stride);
     if (p.win) p.splits = mtn_wgrad3_splits(B, H, W, p.N, Cin, dtype, &p.rows_per_split);
-    else p.splits = mtn_wgrad_splits(p.M, p.N, p.K, Cin, dtype, &p.rows_per_split);
+    else if (mtn_wgrad_row3_ok(dtype, p.N, Cin, ksize, stride)) {
+        p.win = 2;
+        p.splits = mtn_wgrad_row3_splits(p.M, p.N, Cin, dtype, &p.rows_per_split);
+    } else p.splits = mtn_wgrad_splits(p.M, p.N, p.K, Cin, dtype, &p.rows_per_split);
     return 0;
 }
 
@@ -358,6 +361,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 14) { mtn_pose_set_row(value); return MTN_OK; }
     if (key == 15) { mtn_dgrad2_set(value); return MTN_OK; }
     if (key == 16) { mtn_igemm_set_image_tiles(value); return MTN_OK; }
+    if (key == 18) { mtn_wgrad_set_row3(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

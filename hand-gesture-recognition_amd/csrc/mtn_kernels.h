@@ -57,7 +57,7 @@ struct WgradArgs {
     int B, H, W, Cin, OH, OW, KH, KW, stride, pad;
     int M, N, K;
     int splits, rows_per_split;   // win: split of the PADDED SLOT axis, rows_per_split = slots per split
-    int win;                      // 3x3 stride-1 window kernel (wgrad3_kernel)
+    int win;                      // 1: 3x3 stride-1 window kernel (wgrad3_kernel); 2: kernel-row tiles (wgrad_row3_kernel)
     unsigned y_bytes, x_bytes;    // filled by mtn_wgrad_run: byte extents of dY / X (buffer descriptors)
     unsigned magic_ow, magic_oh;  // filled by mtn_wgrad_run: multiply-high divisors of the pixel walk
 };
@@ -168,6 +168,9 @@ int mtn_igemm_read_stamps(void* dst, size_t bytes);
 void mtn_wgrad_set_tile(int t);
 void mtn_wgrad_set_slots(int n);
 void mtn_wgrad_set_win(int on);
+void mtn_wgrad_set_row3(int on);
+int mtn_wgrad_row3_ok(int dtype, int N, int Cin, int ksize, int stride);
+int mtn_wgrad_row3_splits(int M, int N, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad3_ok(int dtype, int H, int W, int ksize, int stride);
 int mtn_wgrad3_splits(int B, int H, int W, int N, int Cin, int dtype, int* slots_per_split);
 void mtn_conv1_set_grid_cap(int n);

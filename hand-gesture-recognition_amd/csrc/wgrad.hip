@@ -467,6 +467,126 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) 
             }
 }
 
+
+// ---- 3x3 taps, any stride, 64-channel input slabs: the three taps of ONE kernel row per workgroup --------------
+// wgrad_dma_kernel gives every tap its own workgroup, so a layer with Cin = 64 (conv2: 128 x 64 tiles, nine
+// of them per split) streams the same dY rows nine times through L2 -> LDS and spends two 8-row gather
+// instructions per wave and step on 16 MFMAs (the gathered X tile costs 2.5x the dY
+// tile).  Here a workgroup owns the taps (kh, 0..2) of one 64-channel slab: ONE dY tile per step feeds three
+// X tiles -- adjacent pixels of the same input rows -- and 48 MFMAs per wave; a third of the workgroups,
+// each with three times the reduction work per DMA instruction.  128 x (3 x 64) output tile, 4 waves
+// (32 dY columns each, all 192 X columns), two stages of [64 rows][128 + 192 columns] = 80 KB: 2 workgroups / CU.
+template <class T>
+__global__ __launch_bounds__(256) void wgrad_row3_kernel(WgradArgs p) {
+    constexpr int BN = 128, BC = 64, NW = 4, TAPS = 3;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BMR = 128 / (int)sizeof(T);
+    constexpr int KI = Mma<T>::KI;
+    constexpr int CPRY = BN / VEC, CPRX = BC / VEC;
+    constexpr int RPBY = 64 / CPRY, RPBX = 64 / CPRX;
+    constexpr int IY = BMR / RPBY / NW, IX = BMR / RPBX / NW;
+    constexpr int WM = BN / NW, FM = WM / 16, FN = BC / 16;
+    static_assert(BMR % (RPBY * NW) == 0 && BMR % (RPBX * NW) == 0, "DMA mapping");
+
+    MTN_DYN_SMEM(smem);
+    T* const sY = reinterpret_cast<T*>(smem);          // [2][BMR][BN]
+    T* const sX = sY + 2 * BMR * BN;                   // [2][TAPS][BMR][BC]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    const int tiles_n = p.N / BN, slabs = p.Cin / BC;
+    const int tiles = tiles_n * p.KH * slabs;
+    int tile, split;
+    {   // (split, tile) order as in wgrad_dma_kernel: the tiles of one split share an XCD's L2
+        const int L = blockIdx.x;
+        if (p.splits % 8 == 0 && tiles <= 24) {
+            const int xcd = L & 7, j = L >> 3;
+            split = (j / tiles) * 8 + xcd;
+            tile = j % tiles;
+        } else {
+            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+            const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+            split = lin / tiles;
+            tile = lin % tiles;
+        }
+    }
+    const int tile_n = tile % tiles_n, tk = tile / tiles_n;
+    const int kh = tk / slabs, c0 = (tk - kh * slabs) * BC;
+    const int n0 = tile_n * BN;
+    const long m_begin = (long)split * p.rows_per_split;
+    long m_end = m_begin + p.rows_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int steps = (int)((m_end - m_begin + BMR - 1) / BMR);
+
+    const BufDesc bufY = make_buf(p.dY, p.y_bytes), bufX = make_buf(p.X, p.x_bytes);
+    int yrow[IY], ychunk[IY];
+    MTN_UNROLL for (int i = 0; i < IY; ++i) {
+        yrow[i] = (wid * IY + i) * RPBY + lane / CPRY;
+        ychunk[i] = Swz<T, BN>::fetch_chunk(yrow[i], lane % CPRY);
+    }
+    int xrow[IX], xchunk[IX];
+    PixelPos xpos[IX];
+    MTN_UNROLL for (int i = 0; i < IX; ++i) {
+        xrow[i] = (wid * IX + i) * RPBX + lane / CPRX;
+        xchunk[i] = Swz<T, BC>::fetch_chunk(xrow[i], lane % CPRX);
+        xpos[i] = pixel_of(m_begin + xrow[i], p);
+    }
+    auto dma_tiles = [&](int st, int stage) {
+        const long mb = m_begin + (long)st * BMR;
+        char* y = reinterpret_cast<char*>(sY + stage * BMR * BN);
+        MTN_UNROLL for (int i = 0; i < IY; ++i) {
+            const long m = mb + yrow[i];
+            const unsigned off = (unsigned)(m * p.lddy + n0 + ychunk[i] * VEC) * (unsigned)sizeof(T);
+            buf_glds16(bufY, m < m_end ? off : 0xFFFFFFF0u, y + (wid * IY + i) * 1024);
+        }
+        MTN_UNROLL for (int i = 0; i < IX; ++i) {
+            const long m = mb + xrow[i];
+            const int iy = xpos[i].oy * p.stride - p.pad + kh, ix0 = xpos[i].ox * p.stride - p.pad;
+            const bool oky = (m < m_end) && iy >= 0 && iy < p.H;
+            const unsigned base = (unsigned)(((xpos[i].b * p.H + iy) * p.W + ix0) * p.ldx + c0 + xchunk[i] * VEC) * (unsigned)sizeof(T);
+            MTN_UNROLL for (int t = 0; t < TAPS; ++t) {
+                const int ix = ix0 + t;
+                char* x = reinterpret_cast<char*>(sX + (stage * TAPS + t) * BMR * BC);
+                buf_glds16(bufX, (oky && ix >= 0 && ix < p.W) ? base + (unsigned)(t * p.ldx) * (unsigned)sizeof(T) : 0xFFFFFFF0u,
+                           x + (wid * IX + i) * 1024);
+            }
+            pixel_advance(xpos[i], BMR, p);
+        }
+    };
+
+    f32x4_t acc[TAPS][FM][FN];
+    MTN_UNROLL for (int t = 0; t < TAPS; ++t)
+        MTN_UNROLL for (int i = 0; i < FM; ++i)
+            MTN_UNROLL for (int j = 0; j < FN; ++j) acc[t][i][j] = zero4();
+
+    if (steps > 0) dma_tiles(0, 0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < steps) dma_tiles(st + 1, cur ^ 1);
+        const T* y = sY + cur * BMR * BN;
+        MTN_UNROLL for (int ks = 0; ks < BMR / KI; ++ks) {
+            typename Mma<T>::Frag fa[FM];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) fa[i] = ColFragS<T, BN>::load(y, ks * KI, wid * WM + i * 16, lane);
+            MTN_UNROLL for (int t = 0; t < TAPS; ++t) {
+                const T* x = sX + (cur * TAPS + t) * BMR * BC;
+                typename Mma<T>::Frag fb[FN];
+                MTN_UNROLL for (int j = 0; j < FN; ++j) fb[j] = ColFragS<T, BC>::load(x, ks * KI, j * 16, lane);
+                MTN_UNROLL for (int i = 0; i < FM; ++i)
+                    MTN_UNROLL for (int j = 0; j < FN; ++j) acc[t][i][j] = Mma<T>::mma(fb[j], fa[i], acc[t][i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = p.partial + (long)split * p.N * p.K;
+    MTN_UNROLL for (int t = 0; t < TAPS; ++t)
+        MTN_UNROLL for (int i = 0; i < FM; ++i)
+            MTN_UNROLL for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wid * WM + i * 16 + (lane & 15);
+                const int k = (kh * p.KW + t) * p.Cin + c0 + j * 16 + 4 * (lane >> 4);
+                store4<float>(out + (long)n * p.K + k, acc[t][i][j]);
+            }
+}
+
 // ---- 3x3, stride 1: all nine taps from ONE window of the input -------------------------------------
 // The tiles above re-stream dY and the tap-shifted X once per tap: nine times the bytes through the
 // L2 -> LDS path for the same FLOPs, and that path (64 B/clk/CU) is what bounds them.  Here a
@@ -719,6 +839,19 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
 }
 
 template <class T>
+int launch_wgrad_row3(const WgradArgs& p, hipStream_t stream) {
+    constexpr int BMR = 128 / (int)sizeof(T);
+    constexpr size_t lds = 2 * (size_t)BMR * (128 + 3 * 64) * sizeof(T);
+#ifndef MTN_EMU
+    static MtnLdsAttr attr;
+    mtn_set_max_lds(attr, &wgrad_row3_kernel<T>, lds);
+#endif
+    const int tiles = (p.N / 128) * p.KH * (p.Cin / 64);
+    MTN_LAUNCH(wgrad_row3_kernel<T>, dim3(tiles * p.splits), dim3(256), lds, stream, p);
+    return mtn_check_launch("wgrad_row3");
+}
+
+template <class T>
 int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
     constexpr int KS = Wg3<T>::KS, RPB = Wg3<T>::RPB;
     const int halo = p.W + 2;
@@ -755,6 +888,30 @@ int mtn_wgrad3_splits(int B, int H, int W, int N, int Cin, int dtype, int* slots
     sps = (sps + ks - 1) / ks * ks;
     *slots_per_split = (int)sps;
     return (int)((S + sps - 1) / sps);
+}
+
+// the kernel-row form serves 3x3 layers whose input has ONE 64-channel slab per tap tile anyway (Cin = 64:
+// wgrad_tile picks 128 x 64 there) and 128-wide outputs -- conv2 of the model
+static int g_wgrad_row3 = 1;     // debug key 18
+void mtn_wgrad_set_row3(int on) { g_wgrad_row3 = on; }
+int mtn_wgrad_row3_ok(int dtype, int N, int Cin, int ksize, int stride) {
+    (void)dtype;
+    return g_wgrad_row3 && g_wgrad_dma && ksize == 3 && Cin == 64 && N % 128 == 0 && !(stride == 1 && g_wgrad3);
+}
+int mtn_wgrad_row3_splits(int M, int N, int Cin, int dtype, int* rows_per_split) {
+    const int bmr = dtype == MTN_BF16 ? 64 : 32;
+    const long tiles = (long)(N / 128) * 3 * (Cin / 64);
+    long splits = (g_wgrad_slots > 0 ? g_wgrad_slots : 512) / tiles;      // two workgroups per CU
+    if (splits < 1) splits = 1;
+    if (splits >= 8 && tiles <= 24) splits &= ~7L;
+    const long max_splits = (M + bmr - 1) / bmr;
+    if (splits > max_splits) splits = max_splits;
+    long rps = (M + splits - 1) / splits;
+    rps = (rps + bmr - 1) / bmr * bmr;
+    *rows_per_split = (int)rps;
+    long n = (M + rps - 1) / rps;
+    if (n >= 8 && tiles <= 24) n = (n + 7) / 8 * 8;
+    return (int)n;
 }
 void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
@@ -816,10 +973,12 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE(p.N % 64 == 0 && p.Cin % 64 == 0, "wgrad: N=%d and Cin=%d must be multiples of 64", p.N, p.Cin);
     MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "wgrad: K mismatch");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "wgrad: M mismatch");
-    MTN_REQUIRE(p.win || (p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M),
+    const bool w3 = p.win == 1, row3 = p.win == 2;       // window kernel (padded slot axis) / kernel-row tiles
+    MTN_REQUIRE(w3 || (p.splits >= 1 && p.rows_per_split % bmr == 0 && (long)p.splits * p.rows_per_split >= p.M),
                 "wgrad: bad split (%d x %d rows for M=%d)", p.splits, p.rows_per_split, p.M);
-    MTN_REQUIRE(!p.win || (p.splits >= 1 && (long)p.splits * p.rows_per_split >= (long)p.B * (p.H + 1) * (p.W + 1)),
+    MTN_REQUIRE(!w3 || (p.splits >= 1 && (long)p.splits * p.rows_per_split >= (long)p.B * (p.H + 1) * (p.W + 1)),
                 "wgrad3: bad split (%d x %d slots)", p.splits, p.rows_per_split);
+    MTN_REQUIRE(!row3 || (p.KH == 3 && p.KW == 3 && p.N % 128 == 0), "wgrad_row3: 3x3 layers with 128-wide outputs only");
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
     MTN_REQUIRE((p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) ||
                     (((long)p.M + 128) * p.OW < (1L << 32) && ((long)p.M / p.OW + 128) * p.OH < (1L << 32)),
@@ -833,7 +992,8 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
         p.x_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.ldx + p.Cin) * esz);
     }
     int rc;
-    if (p.win) {
+    if (row3) rc = dtype == MTN_BF16 ? launch_wgrad_row3<bf16_t>(p, stream) : launch_wgrad_row3<float>(p, stream);
+    else if (w3) {
         const unsigned w1 = (unsigned)p.W + 1u, h1 = (unsigned)p.H + 1u;
         MTN_REQUIRE(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W, "wgrad3: 3x3 stride-1 layers only");
         MTN_REQUIRE(((long)p.B * h1 * w1 + 4096) * w1 < (1L << 32), "wgrad3: too many slots for the multiply-high decode");
