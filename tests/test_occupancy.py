@@ -30,6 +30,8 @@ BUDGETS = [
     ("dgrad2_kernel<bf16_t>", 128, "8 waves x 2 workgroups per CU"),
     ("wgrad_dma2_kernel<bf16_t, 128, 128, 4, 2>", 128, "8 waves x 2 workgroups per CU"),
     ("wgrad3_kernel<bf16_t>", 256, "8 waves, one workgroup per CU"),
+    ("wgrad_row3_kernel<bf16_t>", 256, "4 waves x 2 workgroups per CU (80 KB of LDS each)"),
+    ("igemm_kernel<bf16_t, 144, 256, 1, 8, 6, 2>", 256, "image tiles: 8 waves, one workgroup per CU"),
     ("conv1_bwd_kernel<bf16_t, true, true>", 168, "__launch_bounds__(256, 3)"),
 ]
 
@@ -45,7 +47,7 @@ def test_vgpr_budget(regs, prefix, limit, why):
 def test_no_spills_in_the_mfma_kernels(regs):
     """scratch traffic inside a K loop is never acceptable; dgrad2's epilogue is allowed its few dwords"""
     for k, v in regs.items():
-        if k.startswith(("igemm_kernel<bf16_t", "wgrad_dma2_kernel<bf16_t", "wgrad_dma_kernel<bf16_t", "wgrad3_kernel<bf16_t")):
+        if k.startswith(("igemm_kernel<bf16_t", "wgrad_dma2_kernel<bf16_t", "wgrad_dma_kernel<bf16_t", "wgrad3_kernel<bf16_t", "wgrad_row3_kernel<bf16_t")):
             assert v["spill"] == 0, (k, v)
         if k.startswith("dgrad2_kernel<bf16_t"):
             assert v["spill"] <= 32, (k, v)
