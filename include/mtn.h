@@ -258,7 +258,11 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  * key 3 = igemm pipeline (1: register-staged single LDS buffer; 2: register-staged double buffer;
  *         3: LDS-DMA double buffer; 4: LDS-DMA triple buffer with counted vmcnt; 5: window-resident
  *         activations for stride-1 3x3 layers, LDS-DMA double buffer elsewhere);
- * keys 4-8: tile / split overrides of the tuning tools (tools/bench_kernels.py).
+ * keys 4-14: tile / split / kernel-choice overrides of the tuning tools (tools/bench_kernels.py);
+ * key 15 = dgrad2 (all four parities of a 3x3 stride-2 data gradient per workgroup; 0: igemm's
+ *          parity-major rows); key 16 = igemm image tiles (bit 0 on, bit 1 ignore the tile-count floor);
+ * key 18 = kernel-row tiles of the 64-channel 3x3 weight gradient (0: one tap per tile).
+ * The environment variable MTN_DEBUG_KEYS="k=v,k=v" applies keys when the binding loads the library.
  * mtn_debug_read: key 1 = in-kernel phase stamps of the last igemm launch (diagnostic builds with
  * -DMTN_STAMPS only; returns non-zero otherwise). */
 int mtn_debug_set(int key, int value);
