@@ -179,3 +179,28 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
     assert rel_err(dy1, dy0) < tol(dtype, 1e-5, 1e-2)
     if with_bres:
         assert torch.equal(dr1, dr0)
+
+
+def test_conv_dgrad_bn_refuses_bad_operands(be):
+    """Argument errors of the fused hand-over entry fail the call (no launch): a slab sized for another tile
+    count, a missing BatchNorm operand, a residual on a unit without activation."""
+    dtype = torch.float32
+    d = be.device
+    B, H, W, Cin, Cout, k, s = 2, 6, 6, 64, 64, 3, 1
+    dy = _rand((B, H, W, Cout), dtype, 1).to(d)
+    wt = _rand((Cin, k, k, Cout), dtype, 2).to(d)
+    dx = torch.empty((B, H, W, Cin), dtype=dtype, device=d)
+    y = _rand((B, H, W, Cin), dtype, 3).to(d)
+    ss, mr = torch.ones(2, Cin, device=d), torch.ones(2, Cin, device=d)
+    tiles = ops.conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, k, s)
+    part = torch.empty(ops.slab_rows(tiles + 3), 2, Cin, device=d)
+    with pytest.raises(RuntimeError, match="row tiles"):
+        ops.conv_dgrad(dy, wt, dx, None, k, s, bn=(y, None, ss, mr, ops.ACT_SILU, part, tiles + 3))
+    with pytest.raises(RuntimeError, match="BatchNorm"):
+        ops.conv_dgrad(dy, wt, dx, None, k, s, bn=(y, y, ss, mr, ops.ACT_NONE, part, tiles))      # residual needs SiLU
+    with pytest.raises(ValueError, match="shape"):
+        ops.conv_dgrad(dy, wt, dx, None, k, s, bn=(y[..., :32], None, ss, mr, ops.ACT_SILU, part, tiles))
+    with pytest.raises(ValueError, match="slab"):
+        ops.conv_dgrad(dy, wt, dx, None, k, s, bn=(y, None, ss, mr, ops.ACT_SILU, part.flatten()[:10], tiles))
+    ops.conv_dgrad(dy, wt, dx, None, k, s, bn=(y, None, ss, mr, ops.ACT_SILU, part, tiles))          # and the good call goes through
+    be.sync()
