@@ -37,6 +37,7 @@ class Engine:
     def __init__(self, model, batch, dtype):
         self.model, self.B, self.dt = model, int(batch), dtype
         self.dev = model.flat_params.device
+        self.generation = model._generation       # the flat buffers this plan's pointers were taken from
         H, W = model.image_size
         stride = model.encoder.total_stride
         if H % stride or W % stride:
@@ -222,7 +223,17 @@ class Engine:
     def _g(p):
         return p._mtn_grad
 
+    def check_current(self):
+        """A plan caches views of the module's flat parameter / gradient buffers (conv weights, the pack
+        table).  load_state_dict(assign=True), .to() and _flatten() replace those buffers: a plan built
+        before would read stale weights and write gradients nobody consumes -- refuse instead."""
+        if self.generation != self.model._generation:
+            raise RuntimeError("this execution plan was built before the module's parameter storage was replaced "
+                               "(load_state_dict(assign=True) / .to() / _flatten()); take a new one with "
+                               "model.engine(batch) and rebuild the TrainStep")
+
     def pack_weights(self):
+        self.check_current()
         ops.pack_weights(self.model.flat_params, self.wpack, self.pack_desc, self.pack_n, self.pack_max)
 
     def _dy(self, u):
@@ -405,6 +416,7 @@ class Engine:
 
     def backward(self, dlogits=None, dhm=None):
         """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
+        self.check_current()
         dlogits = self.dlogits if dlogits is None else dlogits
         dhm = self.dhm if dhm is None else dhm
         for u in self.units:

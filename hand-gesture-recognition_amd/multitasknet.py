@@ -70,6 +70,7 @@ class MultiTaskNet(nn.Module):
         self.compute_dtype = compute_dtype
         self._engines = {}
         self._anchor = None
+        self._generation = 0
         self._flatten()
 
     # ------------------------------------------------------------------ flat parameter storage
@@ -90,6 +91,9 @@ class MultiTaskNet(nn.Module):
                 p.grad = None
                 off += k
         self.flat_params, self.flat_grads, self.n_params = flat, grads, n
+        # every re-flatten orphans the buffers that existing plans (Engine) and optimizers (TrainStep)
+        # captured: they compare this counter with the one they were built at and refuse to run stale
+        self._generation = getattr(self, "_generation", 0) + 1
         self._engines = {}
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
 

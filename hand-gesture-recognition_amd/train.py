@@ -60,15 +60,19 @@ class MultiTaskCriterion(nn.Module):
 
 
 class JointsMSELoss(nn.Module):
-    """libs/loss.py:4-30 (use_target_weight=True): 0.5 * mean((w (p - t))^2)."""
+    """libs/loss.py:4-30: 0.5 * mean((w (p - t))^2); with ``use_target_weight=False`` the weights
+    are ignored (libs/loss.py:26-28), i.e. w = 1 for every joint."""
 
     def __init__(self, use_target_weight=True):
         super().__init__()
-        if not use_target_weight:
-            raise NotImplementedError("the reference trains with use_target_weight=True (train.py:35)")
+        self.use_target_weight = bool(use_target_weight)
 
-    def forward(self, output, target, target_weight):
+    def forward(self, output, target, target_weight=None):
         B = output.shape[0]
+        if not self.use_target_weight or target_weight is None:
+            if self.use_target_weight:
+                raise ValueError("JointsMSELoss(use_target_weight=True) needs target_weight [B,J,1]")
+            target_weight = torch.ones(B, output.shape[1], 1, device=output.device)
         logits = torch.zeros(B, 1, device=output.device)
         label = torch.zeros(B, dtype=torch.int64, device=output.device)
         return _FusedLoss.apply(logits, output, label, target, target_weight, 0.0)[2]
@@ -98,6 +102,7 @@ class TrainStep:
                  use_graph=False, want_attn=True, overlap_comm=True):
         self.model, self.B = model, int(batch_size)
         self.eng = model.engine(self.B)
+        self.generation = model._generation      # Adam moments are laid out like THIS flat parameter buffer
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         dev = model.flat_params.device
@@ -130,6 +135,10 @@ class TrainStep:
 
     def _fwd_bwd(self, img, label, target, tw):
         e = self.eng
+        if self.generation != self.model._generation:
+            raise RuntimeError("the module's parameter storage was replaced after this TrainStep was built "
+                               "(load_state_dict(assign=True) / .to() / _flatten()): its plan and Adam moments "
+                               "address the old buffers; build a new TrainStep")
         e.forward(img, training=True, want_attn=self.want_attn)
         e.loss(label, target, tw, with_grads=True)
         # the bucket hook lives on the (shared) engine only for the duration of THIS backward: a

@@ -2,6 +2,7 @@
 callbacks), load_state_dict(assign=True), and the lifetime of TrainStep's bucket hook on the shared plan."""
 import copy
 
+import pytest
 import torch
 
 import mtn_oracle as O
@@ -71,3 +72,51 @@ def test_bucket_hook_is_installed_only_during_a_train_step():
     assert fired == [] and step.eng.on_grads_ready is None
     step._fwd_bwd(*batch)
     assert len(fired) == 5
+
+
+def test_train_step_built_before_assign_refuses_to_run_stale():
+    """load_state_dict(assign=True) re-flattens the module; a TrainStep / Engine built before
+    would read the old packed weights and write conv gradients into an orphaned buffer.  Both now raise, and
+    a TrainStep built afterwards trains on the new weights with complete gradients."""
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=8)
+    batch = O.synthetic_batch(2, 32, seed=14)
+    m = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    step = TrainStep(m, 2, lr=1e-3)
+    step(*batch)
+    old_engine = step.eng
+    sd2 = O.synthetic_state_dict(21, 19, seed=9)
+    m.load_state_dict({k: v.clone() for k, v in sd2.items()}, strict=True, assign=True)
+    with pytest.raises(RuntimeError, match="parameter storage was replaced"):
+        step(*batch)
+    with pytest.raises(RuntimeError, match="built before"):
+        old_engine.forward(batch[0])
+    # a fresh step sees every gradient (conv weights included) in the NEW flat buffer
+    step2 = TrainStep(m, 2, lr=1e-3)
+    step2._fwd_bwd(*batch)
+    ref = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    ref.load_state_dict(sd2, strict=True)
+    _, g_ref = _fwd_bwd(ref, batch)
+    assert rel_err(m.flat_grads[:m.n_params], g_ref) < 1e-5      # (fused loss kernel vs torch loss: not bit-equal)
+    conv_w = dict(m.named_parameters())["encoder.cspelan1.cv2.0.cv1.conv.weight"]
+    assert float(conv_w._mtn_grad.abs().max()) > 0
+
+
+def test_joints_mse_without_target_weight():
+    """libs/loss.py:26-28: use_target_weight=False ignores the weights (w = 1)."""
+    import torch.nn.functional as F
+    from hand_gesture_recognition_amd.train import JointsMSELoss
+    Backend("emu")
+    g = torch.Generator().manual_seed(3)
+    out, tgt = torch.randn(3, 5, 8, 8, generator=g), torch.rand(3, 5, 8, 8, generator=g)
+    tw = (torch.rand(3, 5, 1, generator=g) > 0.5).float()
+    out.requires_grad_(True)
+    loss = JointsMSELoss(use_target_weight=False)(out, tgt, tw)
+    ref = sum(0.5 * F.mse_loss(out[:, j], tgt[:, j]) for j in range(5)) / 5          # the reference's loop, no weights
+    assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    loss.backward()
+    gref, = torch.autograd.grad(ref, out)
+    assert rel_err(out.grad, gref) < 1e-5
+    lw = JointsMSELoss(use_target_weight=True)(out.detach(), tgt, tw)
+    assert abs(float(lw) - float(O.joints_mse_loss(out.detach(), tgt, tw))) < 1e-6
