@@ -33,7 +33,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--size", type=int, default=192)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                    help="bf16: bf16 storage + MFMA (BASELINE config 2); fp32: fp32 storage, exact-f32 MFMA; "
+                         "bf16x3: fp32 storage, split-bf16 products (three MFMAs) -- both fp32 modes meet 1e-3")
     ap.add_argument("--graph", type=int, default=0,
                     help="replay the step from a hipGraph (measured equal to eager launch: the step is GPU-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +186,7 @@ def main():
     from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
     from hand_gesture_recognition_amd.train import TrainStep, synthetic_batch
 
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dt = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[a.dtype]
     torch.manual_seed(42)
     model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=dt).to(dev)
     step = TrainStep(model, a.batch, lr=1e-3, use_graph=bool(a.graph))

@@ -54,7 +54,7 @@ void dgrad2_kernel(IgemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 3, wn = wid >> 2;
-    const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
+    const int frow = lane & 15, fg = lane >> 4;
 
     // XCD-aware tile order as in igemm.hip: the N/BN column tiles of one window share an XCD's L2
     const int tiles_n = p.N / BN, nwg = gridDim.x;
@@ -125,11 +125,11 @@ void dgrad2_kernel(IgemmArgs p) {
         }
         typename Mma<T>::Frag fa[2][FM], fb[2][FN];
         auto load = [&](int s, int buf) {
-            const int cs = s / KS, e = (s % KS) * KI + fk;
+            const int cs = s / KS, ks = s % KS;
             MTN_UNROLL for (int j = 0; j < FN; ++j)
-                fb[buf][j] = Mma<T>::load(wb + (cs * BN + j * 16) * BK + (((e / VEC) ^ swb) * VEC) + (e % VEC));
+                fb[buf][j] = RowFrag<T>::load(wb + (cs * BN + j * 16) * BK, ks, fg, swb);
             MTN_UNROLL for (int i = 0; i < FM; ++i)
-                fa[buf][i] = Mma<T>::load(sWin + aoff[i] + cs * acs[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC));
+                fa[buf][i] = RowFrag<T>::load(sWin + aoff[i] + cs * acs[i], ks, fg, asw[i]);
         };
         load(0, 0);
         MTN_UNROLL for (int s = 0; s < NS; ++s) {
@@ -292,5 +292,6 @@ bool mtn_dgrad2_ok(const IgemmArgs& p, int dtype) {
 int mtn_dgrad2_tiles_m(const IgemmArgs& p) { return mtn_cdiv((long)p.B * p.H * p.W, D2_BM); }
 
 int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream) {
+    if (dtype == MTN_F32X3) return launch_dgrad2<f32x3_t>(p, stream);
     return dtype == MTN_BF16 ? launch_dgrad2<bf16_t>(p, stream) : launch_dgrad2<float>(p, stream);
 }

@@ -320,7 +320,8 @@ void igemm_kernel(IgemmArgs p) {
 
     const int KT = ntaps * spt;
     const int frow = lane & 15;
-    const int fk = (lane >> 4) * (KI / 4);
+    const int fg = lane >> 4;              // k group of this lane inside a fragment (RowFrag, mtn_types.h)
+    const int fk = fg * (KI / 4);
 
     // One K step of MFMAs with the fragment reads software-pipelined by hand: W fragments of a
     // k-substep, then A fragments two ahead of the row of MFMAs that consumes them.  The scheduler
@@ -399,8 +400,8 @@ void igemm_kernel(IgemmArgs p) {
             aoff[i] = ok ? (WOFF + cs * WR8 + j) * BK : (WOFF + CS * WR8) * BK;
             asw[i] = j & 7;
         }
-        mma_step([&](int ks, int i) { const int e = ks * KI + fk; return Mma<T>::load(sB + aoff[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC)); },
-                 [&](int ks, int j) { const int e = ks * KI + fk; return Mma<T>::load(b + j * 16 * BK + (((e / VEC) ^ swb) * VEC) + (e % VEC)); });
+        mma_step([&](int ks, int i) { return RowFrag<T>::load(sB + aoff[i], ks, fg, asw[i]); },
+                 [&](int ks, int j) { return RowFrag<T>::load(b + j * 16 * BK, ks, fg, swb); });
     };
 
     auto compute = [&](int stage) {
@@ -409,9 +410,8 @@ void igemm_kernel(IgemmArgs p) {
             const T* a = sA + stage * BM * BK + (wm * WM + frow) * BK;
             const T* b = sB + stage * BN * BK + (wn * WN + frow) * BK;
             const int sw = frow & 7;                       // (row & 7): tile bases are multiples of 16
-            auto off = [&](int ks) { const int e = ks * KI + fk; return (((e / VEC) ^ sw) * VEC) + (e % VEC); };
-            mma_step([&](int ks, int i) { return Mma<T>::load(a + i * 16 * BK + off(ks)); },
-                     [&](int ks, int j) { return Mma<T>::load(b + j * 16 * BK + off(ks)); });
+            mma_step([&](int ks, int i) { return RowFrag<T>::load(a + i * 16 * BK, ks, fg, sw); },
+                     [&](int ks, int j) { return RowFrag<T>::load(b + j * 16 * BK, ks, fg, sw); });
             return;
         }
         const T* a = sA + stage * BM * PITCH + (wm * WM + frow) * PITCH + fk;
@@ -457,7 +457,7 @@ void igemm_kernel(IgemmArgs p) {
                 aoff[i] = ok ? (cs * WR8 + j) * BK : CS * WR8 * BK;
                 asw[i] = j & 7;
             }
-            mma_step([&](int ks, int i) { const int e = ks * KI + fk; return Mma<T>::load(sWin + aoff[i] + (((e / VEC) ^ asw[i]) * VEC) + (e % VEC)); },
+            mma_step([&](int ks, int i) { return RowFrag<T>::load(sWin + aoff[i], ks, fg, asw[i]); },
                      [&](int ks, int j) { return wq[slot][ks][j]; });
         };
         MTN_UNROLL for (int d = 0; d + 1 < D; ++d) load_w(d, d);
@@ -868,7 +868,7 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
         p.magic_h = dh > 1 ? (unsigned)(0x100000000ull / dh) + 1u : 0u;
     }
     const int bk = dtype == MTN_BF16 ? 64 : 32;
-    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "igemm: bad dtype %d", dtype);
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "igemm: bad dtype %d", dtype);
     MTN_REQUIRE(p.act != MTN_ACT_GELU_GRAD_ || (igemm_pointwise(p) && g_igemm_stages == 5 && p.aux_out),
                 "igemm: the GELU-backward epilogue exists for 1x1 taps in the default pipeline only");
     MTN_REQUIRE(p.M > 0 && p.N > 0 && p.N % 64 == 0, "igemm: N=%d must be a positive multiple of 64 (M=%d)", p.N, p.M);
@@ -890,5 +890,6 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
                 "igemm: tensor too large for 32-bit byte offsets");
     MTN_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.Wp | (uintptr_t)p.Out | (uintptr_t)p.res | (uintptr_t)p.aux_out) % 16 == 0, "igemm: pointers must be 16-byte aligned");
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
+    if (dtype == MTN_F32X3) return dispatch_igemm<f32x3_t>(p, stream);
     return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);
 }

@@ -5,6 +5,9 @@
 
 #define MTN_F32 MTN_DTYPE_F32
 #define MTN_BF16 MTN_DTYPE_BF16
+#define MTN_F32X3 MTN_DTYPE_F32X3
+// storage type behind a dtype code: everything that is not a GEMM-shaped kernel sees F32X3 as plain F32
+static inline int mtn_storage_dtype(int dtype) { return dtype == MTN_DTYPE_F32X3 ? MTN_DTYPE_F32 : dtype; }
 #define MTN_ACT_GELU_GRAD_ 100     // igemm epilogue only: multiply by gelu'(saved pre-activation)
 
 struct IgemmArgs {

@@ -4,10 +4,16 @@
 //   bf16_t : throughput mode -- bf16 activations/weights, MFMA bf16, fp32 accumulate
 //   float  : validation mode -- fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32),
 //            the mode the 1e-3 parity gate against the fp32 reference is run in.
+//   f32x3_t: fp32 storage like `float` (every elementwise / reduction kernel runs its float
+//            instantiation on it unchanged); the GEMM-shaped kernels (igemm / dgrad2 / wgrad) split each
+//            operand into bf16 hi + bf16 lo IN REGISTERS after the LDS read and multiply with three
+//            bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-17 relative
+//            error per product at 3/16 of the exact-f32 MFMA time -- the 1e-3 gate at throughput.
 #pragma once
 #include "mtn_rt.h"
 
 struct bf16_t { unsigned short v; };
+struct f32x3_t { float v; };
 
 #ifdef MTN_EMU
 typedef emu::bf16x8 bf16x8_t;
@@ -35,8 +41,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // v_cvt_pk_bf16_f32: RNE, k
 template <class T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
+template <> __device__ __forceinline__ float to_f<f32x3_t>(f32x3_t x) { return x.v; }
 template <class T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ f32x3_t from_f<f32x3_t>(float x) { f32x3_t r; r.v = x; return r; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
 // value as it will read back from storage of type T
 template <class T> __device__ __forceinline__ float round_to(float x) { return to_f<T>(from_f<T>(x)); }
@@ -67,6 +75,7 @@ template <> __device__ __forceinline__ void unpack<bf16_t>(const chunk16& c, flo
         f[2 * i] = bf2f(lo); f[2 * i + 1] = bf2f(hi);
     }
 }
+template <> __device__ __forceinline__ void unpack<f32x3_t>(const chunk16& c, float* f) { unpack<float>(c, f); }
 template <class T> __device__ __forceinline__ chunk16 pack(const float* f);
 template <> __device__ __forceinline__ chunk16 pack<float>(const float* f) {
     chunk16 c;
@@ -83,6 +92,7 @@ template <> __device__ __forceinline__ chunk16 pack<bf16_t>(const float* f) {
         c[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
     return c;
 }
+template <> __device__ __forceinline__ chunk16 pack<f32x3_t>(const float* f) { return pack<float>(f); }
 // four consecutive elements from one accumulator quad (dst 8- / 16-byte aligned)
 template <class T> __device__ __forceinline__ void store4(T* dst, const f32x4_t& v);
 template <> __device__ __forceinline__ void store4<float>(float* dst, const f32x4_t& v) {
@@ -102,6 +112,9 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const f3
     o[1] = (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16);
     *reinterpret_cast<u32x2_t*>(dst) = o;
 #endif
+}
+template <> __device__ __forceinline__ void store4<f32x3_t>(f32x3_t* dst, const f32x4_t& v) {
+    store4<float>(reinterpret_cast<float*>(dst), v);
 }
 __device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c[0] = 0u; c[1] = 0u; c[2] = 0u; c[3] = 0u; return c; }
 
@@ -149,12 +162,91 @@ template <> struct Mma<float> {
     }
 };
 
+// fp32 storage, split-bf16 multiply.  One "instruction" = three 16x16x32 bf16 MFMAs over 32 k: lane
+// group g = lane >> 4 holds EIGHT fp32 k-values of its row, split in registers into
+//   hi = bf16_rne(x),  lo = bf16_rne(x - hi)        (x - hi is exact in fp32)
+// and the product is hi*hi + hi*lo + lo*hi (lo*lo ~ 2^-18 |ab| is dropped).  WHICH eight k-values a
+// lane group holds is free as long as both operands use the same assignment (an MFMA sums over k):
+// the row-major LDS tiles of igemm / dgrad2 give group g the 16-byte slots g and g + 4 of the 128-byte
+// row (RowFrag below: conflict-free under the XOR swizzle, where two adjacent slots are 2-way
+// conflicted), the pixel-major tiles of wgrad give it rows g, g + 4, ..., g + 28.
+struct Frag3 { bf16x8_t hi, lo; };
+template <> struct Mma<f32x3_t> {
+    static constexpr int KI = 32;
+    typedef Frag3 Frag;
+    static __device__ __forceinline__ Frag split(const float* x) {       // 8 values
+        Frag f;
+#ifdef MTN_EMU
+        MTN_UNROLL for (int j = 0; j < 8; ++j) {
+            const bf16_t h = f2bf(x[j]);
+            f.hi[j] = h.v;
+            f.lo[j] = f2bf(x[j] - bf2f(h)).v;
+        }
+#else
+        MTN_UNROLL for (int j = 0; j < 8; ++j) {
+            const __bf16 h = (__bf16)x[j];                               // v_cvt_pk_bf16_f32 (RNE)
+            f.hi[j] = h;
+            f.lo[j] = (__bf16)(x[j] - (float)h);
+        }
+#endif
+        return f;
+    }
+    static __device__ __forceinline__ Frag split2(const chunk16& c0, const chunk16& c1) {
+        float x[8];
+        unpack<float>(c0, x);
+        unpack<float>(c1, x + 4);
+        return split(x);
+    }
+    // 8 consecutive k-values at p (16-byte aligned)
+    static __device__ __forceinline__ Frag load(const f32x3_t* p) {
+        const chunk16* q = reinterpret_cast<const chunk16*>(p);
+        return split2(q[0], q[1]);
+    }
+    static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
+#ifdef MTN_EMU
+        c = emu::mfma_16x16x32_bf16(a.lo, b.hi, c);
+        c = emu::mfma_16x16x32_bf16(a.hi, b.lo, c);
+        return emu::mfma_16x16x32_bf16(a.hi, b.hi, c);
+#else
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+#endif
+    }
+};
+
+// Operand fragment of K-sub-step ks from a ROW of an XOR-swizzled row-major LDS tile (128-byte rows of
+// 16-byte slots, slot s of row r stored at slot s ^ (r & 7); `sw` = r & 7, g = lane >> 4).
+template <class T> struct RowFrag {
+    static constexpr int VEC = 16 / (int)sizeof(T), KI = Mma<T>::KI;
+    static __device__ __forceinline__ typename Mma<T>::Frag load(const T* row, int ks, int g, int sw) {
+        const int e = ks * KI + g * (KI / 4);
+        return Mma<T>::load(row + (((e / VEC) ^ sw) * VEC) + (e % VEC));
+    }
+};
+template <> struct RowFrag<f32x3_t> {
+    static __device__ __forceinline__ Frag3 load(const f32x3_t* row, int ks, int g, int sw) {
+        (void)ks;                                                        // KI = 32 = the whole 128-byte row
+        const chunk16 c0 = *reinterpret_cast<const chunk16*>(row + ((g ^ sw) * 4));
+        const chunk16 c1 = *reinterpret_cast<const chunk16*>(row + (((g + 4) ^ sw) * 4));
+        return Mma<f32x3_t>::split2(c0, c1);
+    }
+};
+
 // operand fragment read down the reduction (row) axis of a [rows][pitch] LDS tile;
 // base points at [k0][col0]; lane gets rows k0 + koff.., column col0 + (lane & 15).
 template <class T, bool TR> struct ColFrag;
 template <bool TR> struct ColFrag<float, TR> {
     static __device__ __forceinline__ float load(const float* base, int pitch, int lane) {
         return base[(lane >> 4) * pitch + (lane & 15)];
+    }
+};
+template <bool TR> struct ColFrag<f32x3_t, TR> {     // rows k0 + g + 4 j, j = 0..7
+    static __device__ __forceinline__ Frag3 load(const f32x3_t* base, int pitch, int lane) {
+        const float* p = reinterpret_cast<const float*>(base) + (lane >> 4) * pitch + (lane & 15);
+        float x[8];
+        MTN_UNROLL for (int j = 0; j < 8; ++j) x[j] = p[4 * j * pitch];
+        return Mma<f32x3_t>::split(x);
     }
 };
 template <> struct ColFrag<bf16_t, false> {

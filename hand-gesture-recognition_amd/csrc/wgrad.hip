@@ -198,6 +198,14 @@ template <int ROWE> struct ColFragS<float, ROWE> {
         return tile[Swz<float, ROWE>::off(k0 + (lane >> 4), col0 + (lane & 15))];
     }
 };
+template <int ROWE> struct ColFragS<f32x3_t, ROWE> {       // rows k0 + g + 4 j, j = 0..7 (Mma<f32x3_t>, mtn_types.h)
+    static __device__ __forceinline__ Frag3 load(const f32x3_t* tile, int k0, int col0, int lane) {
+        const float* t = reinterpret_cast<const float*>(tile);
+        float x[8];
+        MTN_UNROLL for (int j = 0; j < 8; ++j) x[j] = t[Swz<float, ROWE>::off(k0 + (lane >> 4) + 4 * j, col0 + (lane & 15))];
+        return Mma<f32x3_t>::split(x);
+    }
+};
 template <int ROWE> struct ColFragS<bf16_t, ROWE> {
     static __device__ __forceinline__ bf16x8_t load(const bf16_t* tile, int k0, int col0, int lane) {
         const int g = lane >> 4, i = lane & 15;
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
             return f;
         } else {
             (void)e0; (void)e1;
-            return ColFragS<float, 64>::load(reinterpret_cast<const float*>(tile), row, col, lane);
+            return ColFragS<T, 64>::load(tile, row, col, lane);
         }
     };
 
@@ -969,7 +977,7 @@ static int wgrad_dispatch(const WgradArgs& p, hipStream_t stream) {
 int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     WgradArgs p = p0;
     const int bmr = dtype == MTN_BF16 ? 64 : 32;
-    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "wgrad: bad dtype %d", dtype);
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "wgrad: bad dtype %d", dtype);
     MTN_REQUIRE(p.N % 64 == 0 && p.Cin % 64 == 0, "wgrad: N=%d and Cin=%d must be multiples of 64", p.N, p.Cin);
     MTN_REQUIRE(p.K == p.KH * p.KW * p.Cin, "wgrad: K mismatch");
     MTN_REQUIRE(p.M == p.B * p.OH * p.OW, "wgrad: M mismatch");
@@ -992,15 +1000,18 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
         p.x_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.ldx + p.Cin) * esz);
     }
     int rc;
-    if (row3) rc = dtype == MTN_BF16 ? launch_wgrad_row3<bf16_t>(p, stream) : launch_wgrad_row3<float>(p, stream);
+    if (row3) rc = dtype == MTN_BF16 ? launch_wgrad_row3<bf16_t>(p, stream)
+                                     : (dtype == MTN_F32X3 ? launch_wgrad_row3<f32x3_t>(p, stream) : launch_wgrad_row3<float>(p, stream));
     else if (w3) {
         const unsigned w1 = (unsigned)p.W + 1u, h1 = (unsigned)p.H + 1u;
         MTN_REQUIRE(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W, "wgrad3: 3x3 stride-1 layers only");
         MTN_REQUIRE(((long)p.B * h1 * w1 + 4096) * w1 < (1L << 32), "wgrad3: too many slots for the multiply-high decode");
         p.magic_ow = (unsigned)(0x100000000ull / w1) + 1u;        // slot / (W+1)
         p.magic_oh = (unsigned)(0x100000000ull / h1) + 1u;        // row / (H+1)
-        rc = dtype == MTN_BF16 ? launch_wgrad3<bf16_t>(p, stream) : launch_wgrad3<float>(p, stream);
+        rc = dtype == MTN_BF16 ? launch_wgrad3<bf16_t>(p, stream)
+                               : (dtype == MTN_F32X3 ? launch_wgrad3<f32x3_t>(p, stream) : launch_wgrad3<float>(p, stream));
     } else if (dtype == MTN_BF16) rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
+    else if (dtype == MTN_F32X3) rc = wgrad_dispatch<f32x3_t, false>(p, stream);
     else rc = wgrad_dispatch<float, false>(p, stream);
     if (rc) return rc;
     const long total = (long)p.N * p.K;

@@ -24,6 +24,22 @@ from . import ops
 _ACT = {True: ops.ACT_SILU, False: ops.ACT_NONE}
 
 
+def _in_plan_mode(fn):
+    """Run an Engine method with ops' fp32-matmul mode set to the plan's (exact-f32 MFMA or split-bf16) and
+    restore the caller's afterwards: the mode is not a property of the fp32 tensors the wrappers see."""
+    import functools
+
+    @functools.wraps(fn)
+    def inner(self, *a, **k):
+        prev = ops._f32_code
+        ops.set_f32_matmul(self.f32_code)
+        try:
+            return fn(self, *a, **k)
+        finally:
+            ops.set_f32_matmul(prev)
+    return inner
+
+
 class _Unit:
     """One Conv2d(+BatchNorm) site and its per-layer buffers."""
 
@@ -35,7 +51,9 @@ class _Unit:
 
 class Engine:
     def __init__(self, model, batch, dtype):
-        self.model, self.B, self.dt = model, int(batch), dtype
+        from .multitasknet import resolve_compute_dtype
+        self.model, self.B = model, int(batch)
+        self.dt, self.f32_code = resolve_compute_dtype(dtype)      # storage dtype, how fp32 operands are multiplied
         self.dev = model.flat_params.device
         self.generation = model._generation       # the flat buffers this plan's pointers were taken from
         H, W = model.image_size
@@ -64,6 +82,7 @@ class Engine:
     def _f32(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
 
+    @_in_plan_mode
     def _build(self):
         B, enc = self.B, self.model.encoder
         H2, W2 = self.H // 2, self.W // 2
@@ -232,6 +251,7 @@ class Engine:
                                "(load_state_dict(assign=True) / .to() / _flatten()); take a new one with "
                                "model.engine(batch) and rebuild the TrainStep")
 
+    @_in_plan_mode
     def pack_weights(self):
         self.check_current()
         ops.pack_weights(self.model.flat_params, self.wpack, self.pack_desc, self.pack_n, self.pack_max)
@@ -281,6 +301,7 @@ class Engine:
             self._dgrad(u, dy, g_in, g_in_res, nxt)
 
     # ---------------------------------------------------------------- forward
+    @_in_plan_mode
     def backbone_forward(self, x, training=True):
         """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512]."""
         u1, bn1 = self.u_conv1, self.u_conv1.mod.bn
@@ -313,6 +334,7 @@ class Engine:
                 cur = st["dn"]
         return cur
 
+    @_in_plan_mode
     def forward(self, x, training=True, want_attn=True):
         """MultiTaskNet.forward (model/multitasknet.py:24-29) -> (logits, heatmaps, attnmap)."""
         assert tuple(x.shape) == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
@@ -346,6 +368,7 @@ class Engine:
         return self.logits, self.hm, (self.attn if want_attn else None)
 
     # ---------------------------------------------------------------- loss
+    @_in_plan_mode
     def loss(self, label, target, target_weight, with_grads=True):
         """total = 0.001*CE + JointsMSE (train.py:63-64,75); fills dlogits/dhm when with_grads.
         The batch tensors follow libs/load.py (label int64 [B], target f32 [B,J,H/4,W/4],
@@ -361,6 +384,7 @@ class Engine:
         return self.losses
 
     # ---------------------------------------------------------------- backward
+    @_in_plan_mode
     def backbone_backward(self, g_feats):
         """Backward of backbone_forward given the gradient of its NHWC output (written into g buffers)."""
         for st in self.stages:          # (entered directly: no hand-over can be pending for the backbone's units except the
@@ -414,6 +438,7 @@ class Engine:
                       self._g(u1.weight), _ACT[u1.act])
         self._ready("stem")
 
+    @_in_plan_mode
     def backward(self, dlogits=None, dhm=None):
         """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
         self.check_current()

@@ -12,8 +12,9 @@ Deviations from the reference module, all deliberate:
   * parameter gradients are written (not accumulated) into ``p.grad`` by each backward -- the
     reference's loop zeroes them every step (Lightning), so training is unaffected;
   * the input needs no gradient (none is produced);
-  * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode)
-    or fp32 storage / exact-f32 MFMA (validation mode, the one held to 1e-3 of the reference).
+  * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode),
+    fp32 storage / exact-f32 MFMA (validation mode), or "bf16x3": fp32 storage with split-bf16 matrix
+    products (three MFMAs per product) -- both fp32-storage modes are held to 1e-3 of the reference.
 """
 import copy
 import os
@@ -26,7 +27,23 @@ from .engine import Engine
 from .gelan import GELANNet
 from .transformer import ViT
 
-_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
+           "bf16x3": "bf16x3"}
+
+
+def resolve_compute_dtype(compute_dtype):
+    """compute_dtype -> (storage torch dtype, fp32 matmul code of ops).  torch.bfloat16: bf16 storage and
+    MFMA; torch.float32: fp32 storage, exact-f32 MFMA; "bf16x3": fp32 storage, every matrix product as
+    three bf16 MFMAs on operands split hi + lo in registers (the reference trains in fp32 with TF32
+    matmuls allowed, train.py:19,230: this mode is ~2^-17 per product, tighter than TF32's 2^-11)."""
+    from . import ops
+    if isinstance(compute_dtype, str):
+        compute_dtype = _DTYPES[compute_dtype.lower()]
+    if compute_dtype == "bf16x3":
+        return torch.float32, ops.F32X3
+    if compute_dtype in (torch.bfloat16, torch.float32):
+        return compute_dtype, ops.F32
+    raise ValueError(f"compute_dtype must be torch.bfloat16, torch.float32 or 'bf16x3', got {compute_dtype!r}")
 
 
 class _PlanFunction(torch.autograd.Function):
@@ -67,6 +84,9 @@ class MultiTaskNet(nn.Module):
         self.image_size = (int(image_size[0]), int(image_size[1]))
         if compute_dtype is None:
             compute_dtype = _DTYPES[os.environ.get("MTN_COMPUTE_DTYPE", "bf16").lower()]
+        if isinstance(compute_dtype, str):
+            compute_dtype = _DTYPES[compute_dtype.lower()]
+        resolve_compute_dtype(compute_dtype)               # (validates)
         self.compute_dtype = compute_dtype
         self._engines = {}
         self._anchor = None
@@ -143,6 +163,9 @@ class MultiTaskNet(nn.Module):
                 p.grad = p._mtn_grad
 
     def set_compute_dtype(self, dtype):
+        if isinstance(dtype, str):
+            dtype = _DTYPES[dtype.lower()]
+        resolve_compute_dtype(dtype)
         self.compute_dtype = dtype
         self._engines = {}
         return self

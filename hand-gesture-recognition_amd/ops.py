@@ -8,13 +8,32 @@ import torch
 
 from . import lib
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+# How fp32 tensors are multiplied by the GEMM-shaped kernels: F32 = exact-f32 MFMA, F32X3 = split-bf16
+# (three bf16 MFMAs per product; include/mtn.h MTN_DTYPE_F32X3).  Storage is fp32 either way, so the
+# choice cannot be read off a tensor: the execution plan (Engine) selects it before it launches.
+_f32_code = F32
+
+
+def set_f32_matmul(code):
+    global _f32_code
+    if code not in (F32, F32X3):
+        raise ValueError(f"fp32 matmul mode {code}")
+    _f32_code = code
+
+
+def code_of(dtype):
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float32:
+        return _f32_code
+    raise TypeError(f"unsupported storage dtype {dtype}")
 
 
 def dtype_code(t):
-    return _DT[t.dtype]
+    return code_of(t.dtype)
 
 
 def _stream(t):
@@ -43,7 +62,7 @@ def conv_stats_tiles(M, cout, K):
 
 def conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
     """rows of the partial-statistics slab conv_fwd writes for this layer geometry."""
-    return lib.call("mtn_conv_fwd_stats_tiles", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
+    return lib.call("mtn_conv_fwd_stats_tiles", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
 
 
 def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
@@ -65,7 +84,7 @@ def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
 
 
 def conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
-    return lib.call("mtn_conv_dgrad_bn_tiles", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
+    return lib.call("mtn_conv_dgrad_bn_tiles", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
 
 
 def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None):
@@ -126,7 +145,7 @@ def linear_gelu_bwd(dh, wt, a, da, partial, tiles, dbias):
 
 
 def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride):
-    return lib.call("mtn_conv_wgrad_workspace_bytes", _DT[dtype], B, H, W, Cin, Cout, ksize, stride)
+    return lib.call("mtn_conv_wgrad_workspace_bytes", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
 
 
 def conv_wgrad(x, dy, dw, workspace, ksize, stride):
@@ -142,7 +161,7 @@ def conv_wgrad(x, dy, dw, workspace, ksize, stride):
 
 
 def linear_wgrad_workspace_bytes(dtype, M, N, K):
-    return lib.call("mtn_linear_wgrad_workspace_bytes", _DT[dtype], M, N, K)
+    return lib.call("mtn_linear_wgrad_workspace_bytes", code_of(dtype), M, N, K)
 
 
 def linear_wgrad(x, dy, dw, workspace):

@@ -280,7 +280,7 @@ def build_parser():
     p.add_argument("--save_dir", type=str, default="output")
     p.add_argument("--num_workers", type=int, default=8)
     p.add_argument("--steps_per_epoch", type=int, default=10, help="synthetic steps per epoch")
-    p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32", "bf16x3"])
     return p
 
 
@@ -295,7 +295,7 @@ def run(args, data_cfg):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl")
     torch.manual_seed(42)                                                                 # train.py:21
-    dt = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    dt = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.compute_dtype]
     model = MultiTaskNet(data_cfg["num_joints"], data_cfg["num_classes"], args.image_size, compute_dtype=dt).cuda()
     step = TrainStep(model, args.batch_size, lr=args.lr, lr_step=args.lr_step, lr_factor=args.lr_factor)
     rank = dist.get_rank() if world > 1 else 0

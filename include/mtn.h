@@ -12,7 +12,13 @@
  *     no allocation, no synchronisation, no retained pointers -> safe under hipGraph capture.
  *   - the caller (PyTorch) owns every buffer incl. workspaces (`*_workspace_bytes` sizes them).
  *   - dtype: MTN_DTYPE_F32 = fp32 storage + exact-f32 MFMA (validation mode),
- *            MTN_DTYPE_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation (throughput mode).
+ *            MTN_DTYPE_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation (throughput mode),
+ *            MTN_DTYPE_F32X3 = fp32 storage exactly like MTN_DTYPE_F32; the GEMM-shaped entry points
+ *            (mtn_conv_fwd / _dgrad / _dgrad_bn / _wgrad, mtn_linear_fwd / _gelu_bwd / _wgrad) split both
+ *            operands into bf16 hi + lo in registers and multiply with three bf16 MFMAs per product
+ *            (fp32 accumulate; ~2^-17 relative error per product) -- the 1e-3 tolerance of the reference's
+ *            fp32 training (train.py:19,230: fp32 with TF32 matmuls allowed) at throughput.  Every other
+ *            entry point treats it as MTN_DTYPE_F32.
  *     Statistics, gradients of parameters, optimizer state and losses are always fp32.
  *   - activations are NHWC ("channels last") / token-major [rows][channels]; `ld*` is the
  *     element stride between consecutive rows (pixels), so an op can read or write a channel
@@ -30,6 +36,7 @@ extern "C" {
 
 #define MTN_DTYPE_F32 0
 #define MTN_DTYPE_BF16 1
+#define MTN_DTYPE_F32X3 2
 #define MTN_ACT_NONE 0
 #define MTN_ACT_SILU 1
 #define MTN_ACT_GELU 2
