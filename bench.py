@@ -5,13 +5,23 @@
 A "step" = forward + 0.001*CE + JointsMSE + backward (+ RCCL gradient all-reduce) + AdamW on one
 synthetic batch already resident in HBM; workload = BASELINE.json configs[1]: MultiTaskNet
 (hagrid.yaml: 21 joints, 19 classes) 192x192, B=256 per GPU, bf16 storage / fp32 accumulate.
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the MFMA implicit-GEMM template
-`igemm_kernel`, all instances, timed live with events on the launch stream in an extra
-instrumented step after the timed region) and `cpu_baseline` (the oracle on the host cores).
+Prints ONE JSON line on rank 0:
+  value / ms_per_step   exactly K steps between two barrier + synchronize brackets (max over ranks);
+  timing_windows        4 more windows of K steps each (min / median: boxes of the pool differ by +-4 %);
+  roofline              dominant kernel = the MFMA implicit-GEMM template `igemm_kernel`, all instances, timed
+                        live with events on the launch stream in one instrumented step after the timed region;
+  validation            the SAME step in the two fp32-storage modes that meet the north-star tolerance 1e-3
+                        (bf16x3 = split-bf16 products, fp32 = exact-f32 MFMA): images/sec at the same batch, and
+                        the measured errors of all three modes against the CPU oracle at BASELINE config 1 (B=4);
+  configs               BASELINE configs 4 (384x384, B=128: attention stress) and 5 (GELAN only, B=512: conv HBM
+                        stress): images/sec + the roofline figure of the kernel family each one stresses;
+  cpu_baseline          the oracle (CPU port of the reference path) on the host cores;
+  ranks (N > 1)         rccl_ranks, per-rank ms/step, comm_exposed_ms (time the compute stream waited for RCCL).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -24,6 +34,9 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (same guide: ~6.3 TB/s achievable)
 TRAIN_GFLOP_PER_IMG = 13.09        # fwd + dgrad + wgrad @192^2
+TRAIN_GFLOP_PER_IMG_384 = 55.4
+BACKBONE_GFLOP_PER_IMG = 11.27
+BACKBONE_MB_PER_IMG = 3 * 15.3     # conv part of the one-read-one-write byte model, x3 for the train step
 
 
 def parse():
@@ -38,9 +51,15 @@ def parse():
                          "bf16x3: fp32 storage, split-bf16 products (three MFMAs) -- both fp32 modes meet 1e-3")
     ap.add_argument("--graph", type=int, default=0,
                     help="replay the step from a hipGraph (measured equal to eager launch: the step is GPU-bound)")
+    ap.add_argument("--windows", type=int, default=4, help="extra timing windows of --steps steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-validation", action="store_true")
+    ap.add_argument("--no-configs", action="store_true")
     return ap.parse_args()
+
+
+_DT = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
 
 
 def igemm_roofline(step, batch):
@@ -67,7 +86,7 @@ def igemm_roofline(step, batch):
     def nbytes(*ts):
         return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
-    def g_fwd(x, w, y, stats, k, s, stats_tiles=None):
+    def g_fwd(x, w, y, stats, k, s, stats_tiles=None, **kw):
         Cin, Cout, M = x.shape[-1], y.shape[-1], y.numel() // y.shape[-1]
         return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y), k
 
@@ -144,12 +163,126 @@ def igemm_roofline(step, batch):
             "share_of_step_ms": round(secs * 1e3, 3), "families": families}
 
 
-def cpu_baseline(size):
+def _timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def validation(a, dev, oracle_ref):
+    """The same training step in the fp32-storage modes (north-star tolerance 1e-3), and every mode's measured
+    error against the CPU oracle at BASELINE config 1 (B=4, 192x192; `oracle_ref` comes from the cpu_baseline leg:
+    the oracle is the checker here, never the thing measured)."""
+    from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+    from hand_gesture_recognition_amd.train import TrainStep, synthetic_batch
+    out = {"tolerance": "north_star: logits / heatmaps within 1e-3 (max-norm relative) of the reference's fp32 CPU outputs",
+           "batch": a.batch}
+    for mode in ("bf16x3", "fp32"):
+        torch.manual_seed(42)
+        model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=_DT[mode]).to(dev)
+        step = TrainStep(model, a.batch, lr=1e-3)
+        batch = synthetic_batch(a.batch, (a.size, a.size), 21, 19, dev, 1234)
+        t = _timed(lambda: step(*batch), 8 if mode == "bf16x3" else 5, 2)
+        out[mode] = {"images_per_sec": round(a.batch / t, 1), "ms_per_step": round(t * 1e3, 3)}
+        del step, model, batch
+        torch.cuda.empty_cache()
+    if oracle_ref is not None:
+        import mtn_oracle as O
+        sd, batch, (oc, oh, oa), (ot, _, _), og = oracle_ref
+        errs = {}
+        for mode in ("bf16", "bf16x3", "fp32"):
+            m = MultiTaskNet(21, 19, [192, 192], compute_dtype=_DT[mode])
+            m.load_state_dict(sd, strict=True)
+            m.to(dev).train()
+            img, label, target, tw = (t.to(dev) for t in batch)
+            c, h, at = m(img)
+            tot, _, _ = O.total_loss(c, h, label, target, tw)
+            tot.backward()
+            torch.cuda.synchronize()
+            errs[mode] = {"logits": float(f"{_rel(c, oc):.2e}"), "heatmaps": float(f"{_rel(h, oh):.2e}"),
+                          "attnmap": float(f"{_rel(at, oa):.2e}"),
+                          "total_loss": float(f"{abs(float(tot) - float(ot)) / abs(float(ot)):.2e}"),
+                          "worst_param_grad": float(f"{max(_rel(p.grad, og[k]) for k, p in m.named_parameters()):.2e}")}
+            del m
+        out["errors_vs_oracle_config1_b4"] = errs
+        out["meets_1e-3_on_outputs"] = {m: bool(max(e["logits"], e["heatmaps"], e["attnmap"], e["total_loss"]) < 1e-3) for m, e in errs.items()}
+    return out
+
+
+def config4(dev, steps=10, warmup=3):
+    """BASELINE config 4: MultiTaskNet 384x384 (N = 577 tokens), B=128, bf16 train step; the kernel family it
+    stresses is attention (forward 4 B H N^2 D flops, backward 10 B H N^2 D), timed alone at this shape."""
+    from hand_gesture_recognition_amd import ops
+    from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+    from hand_gesture_recognition_amd.train import TrainStep, synthetic_batch
+    B, S = 128, 384
+    torch.manual_seed(42)
+    model = MultiTaskNet(21, 19, [S, S], compute_dtype=torch.bfloat16).to(dev)
+    step = TrainStep(model, B, lr=1e-3)
+    batch = synthetic_batch(B, (S, S), 21, 19, dev, 1234)
+    t = _timed(lambda: step(*batch), steps, warmup)
+    N, H, D = 577, 8, 32
+    eng = step.eng
+    L = eng.layers[0]
+    tf = _timed(lambda: ops.attention_fwd(L["qkvb"], L["ao"], L["lse"], None, B, N, H, D, D ** -0.5), 20, 3)
+    tb = _timed(lambda: ops.attention_bwd(L["qkvb"], L["ao"], eng.t_a, L["lse"], eng.delta, eng.t_qkv, B, N, H, D, D ** -0.5), 20, 3)
+    ffl, bfl = 4.0 * B * H * N * N * D, 10.0 * B * H * N * N * D
+    ach = (ffl + bfl) / (tf + tb) / 1e12
+    return {"workload": "MultiTaskNet 384x384 (577 tokens) B=128 bf16 train step", "images_per_sec": round(B / t, 1),
+            "ms_per_step": round(t * 1e3, 3), "algorithmic_tflops": round(B / t * TRAIN_GFLOP_PER_IMG_384 / 1e3, 1),
+            "roofline": {"kernel": "attn_fwd_kernel + attn_bwd_dq/dkv_kernel (one layer, timed alone)", "bound": "mfma",
+                         "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "attention_fwd_us": round(tf * 1e6, 1), "attention_fwd_tflops": round(ffl / tf / 1e12, 1),
+                         "attention_bwd_us": round(tb * 1e6, 1), "attention_bwd_tflops": round(bfl / tb / 1e12, 1)}}
+
+
+def config5(dev, steps=10, warmup=3):
+    """BASELINE config 5: GELAN backbone only, 192x192, B=512, bf16 forward + backward with a synthetic upstream
+    gradient (conv HBM stress): roofline = algorithmic bytes of the conv stack / step time."""
+    from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+    B, S = 512, 192
+    torch.manual_seed(42)
+    model = MultiTaskNet(21, 19, [S, S], compute_dtype=torch.bfloat16).to(dev)
+    eng = model.engine(B)
+    x = torch.randn(B, 3, S, S, device=dev)
+    up = torch.randn(B, 12, 12, 512, device=dev).to(torch.bfloat16)
+    gbuf = eng.stages[-1]["g_out"]
+
+    def step():
+        eng.pack_weights()
+        eng.backbone_forward(x, training=True)
+        gbuf.copy_(up)
+        eng.backbone_backward(gbuf)
+
+    t = _timed(step, steps, warmup)
+    gbs = B * BACKBONE_MB_PER_IMG * 1e6 / t / 1e9
+    return {"workload": "GELANNet('small') only, 192x192 B=512 bf16 forward+backward (synthetic upstream gradient)",
+            "images_per_sec": round(B / t, 1), "ms_per_step": round(t * 1e3, 3),
+            "algorithmic_tflops": round(B / t * BACKBONE_GFLOP_PER_IMG / 1e3, 1),
+            "roofline": {"kernel": "whole conv stack (igemm / dgrad2 / wgrad / BatchNorm passes)", "bound": "hbm",
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "algorithmic_mb_per_image": BACKBONE_MB_PER_IMG,
+                         "mfma_frac": round(B / t * BACKBONE_GFLOP_PER_IMG / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)}}
+
+
+def cpu_baseline(size, want_ref):
     """The oracle (CPU port of the reference path) timed on this box's host cores.
 
     Threads = the box's CPU share for one GPU (16): measured on the MI355X host, torch-CPU runs this
     model fastest at 16 threads (8: 53, 16: 68, 32: 33, 64: 18, 256: 0.1 img/s -- oversubscription).
-    Sample: ~10 s of B=16 training steps of the same workload shape.
+    Sample: ~10 s of B=16 training steps of the same workload shape.  With `want_ref` the leg also returns
+    the oracle's outputs / losses / gradients at BASELINE config 1 (B=4) for `validation` to check against.
     """
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mtn_oracle as O
@@ -165,9 +298,15 @@ def cpu_baseline(size):
         O.train_step(sd, batch, st, 1e-3)
         n += 1
     dt = time.perf_counter() - t0
+    ref = None
+    if want_ref:
+        sd1 = O.synthetic_state_dict(21, 19, seed=0)
+        b1 = O.synthetic_batch(4, 192, seed=42)
+        outs, losses, grads = O.forward_backward({k: v.clone() for k, v in sd1.items()}, b1)
+        ref = (sd1, b1, outs, losses, grads)
     return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"{n} train steps (fwd+loss+bwd+AdamW) at B={B}, {size}x{size}, fp32, oracle/mtn_oracle.py "
-                      f"(torch-CPU ops), {threads} threads of {os.cpu_count()} logical CPUs"}
+                      f"(torch-CPU ops), {threads} threads of {os.cpu_count()} logical CPUs"}, ref
 
 
 def main():
@@ -186,37 +325,57 @@ def main():
     from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
     from hand_gesture_recognition_amd.train import TrainStep, synthetic_batch
 
-    dt = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[a.dtype]
     torch.manual_seed(42)
-    model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=dt).to(dev)
+    model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=_DT[a.dtype]).to(dev)
     step = TrainStep(model, a.batch, lr=1e-3, use_graph=bool(a.graph))
     batch = synthetic_batch(a.batch, (a.size, a.size), 21, 19, dev, 1234 + rank)
 
+    def bracket():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def window():
+        """exactly a.steps steps between two barrier + synchronize brackets -> (max over ranks, this rank) seconds"""
+        bracket()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            losses = step(*batch)
+        bracket()
+        mine = time.perf_counter() - t0
+        el = torch.tensor([mine], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el), mine, losses
+
     for _ in range(a.warmup):
         step(*batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = step(*batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed)
+    elapsed, mine, losses = window()                   # THE timed region
     loss_val = [float(x) for x in losses]
     assert all(x == x and abs(x) < 1e6 for x in loss_val), f"non-finite losses {loss_val}"
+    # per-rank step time of the timed region, and how much of the all-reduce the backward did not hide
+    rank_ms = torch.zeros(world, device=dev, dtype=torch.float64)
+    rank_ms[rank] = mine / a.steps * 1e3
+    comm_ms = torch.zeros(world, device=dev, dtype=torch.float64)
+    if world > 1:
+        step.comm_events = []
+        for _ in range(min(a.steps, 10)):
+            step(*batch)
+        torch.cuda.synchronize()
+        comm_ms[rank] = step.comm_exposed_ms()
+        step.comm_events = None
+        dist.all_reduce(rank_ms)
+        dist.all_reduce(comm_ms)
+    extra = [window()[0] / a.steps * 1e3 for _ in range(max(0, a.windows))]
 
     roof = None
     if not a.no_roofline and a.dtype == "bf16":
         roof = igemm_roofline(step, batch)          # every rank runs it (the step holds a collective)
     if rank == 0:
         ips = world * a.batch * a.steps / elapsed
+        gflop = TRAIN_GFLOP_PER_IMG if a.size == 192 else (TRAIN_GFLOP_PER_IMG_384 if a.size == 384 else None)
+        all_ms = [elapsed / a.steps * 1e3] + extra
         out = {
             "metric": f"images/sec training step, MultiTaskNet {a.size}x{a.size} B={a.batch}", "value": round(ips, 1),
             "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -225,13 +384,35 @@ def main():
             "config": {"workload": f"MultiTaskNet(21 joints, 19 classes) {a.size}x{a.size} train step "
                                    f"(fwd + 0.001*CE + JointsMSE + bwd + AdamW), B={a.batch}/GPU, random-init weights",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "hipgraph": bool(a.graph)},
-            "algorithmic_tflops": round(ips * TRAIN_GFLOP_PER_IMG / 1e3, 1) if a.size == 192 else None,
+            "algorithmic_tflops": round(ips * gflop / 1e3, 1) if gflop else None,
+            "mfma_frac_whole_step": round(ips * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS / world, 4) if gflop else None,
             "final_losses": [round(x, 6) for x in loss_val],
+            "timing_windows": {"ms_per_step": [round(x, 3) for x in all_ms], "min": round(min(all_ms), 3),
+                               "median": round(statistics.median(all_ms), 3),
+                               "images_per_sec_at_median": round(world * a.batch / statistics.median(all_ms) * 1e3, 1),
+                               "note": "window 0 is the timed region `value` is computed from"},
         }
+        if world > 1:
+            out["ranks"] = {"rccl_ranks": world, "backend": dist.get_backend(), "ms_per_step_per_rank": [round(float(x), 3) for x in rank_ms],
+                            "comm_exposed_ms_per_rank": [round(float(x), 4) for x in comm_ms],
+                            "comm_exposed_ms": round(float(comm_ms.max()), 4),
+                            "gradient_bytes_all_reduced": int(model.n_params * 4), "buckets": len(step._buckets),
+                            "overlap_with_backward": bool(step.overlap)}
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.size)
+    del step, model
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        base, ref = (None, None)
+        if not a.no_cpu_baseline:
+            base, ref = cpu_baseline(a.size, want_ref=not a.no_validation)
+        if not a.no_validation:
+            out["validation"] = validation(a, dev, ref)
+        if not a.no_configs and a.dtype == "bf16":
+            out["configs"] = {"4": config4(dev), "5": config5(dev)}
+        if base is not None:
+            out["cpu_baseline"] = base
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -124,6 +124,9 @@ class TrainStep:
         # overlap_comm="force" runs the bucketed path on a one-rank group too (RCCL smoke test)
         self.overlap = bool(overlap_comm) and not use_graph and (self.world > 1 or (
             overlap_comm == "force" and dist.is_available() and dist.is_initialized()))
+        # instrumentation (bench.py --gpus N): event pairs around the wait for the gradient all-reduce on
+        # the compute stream; their elapsed time is the communication the backward pass did NOT hide
+        self.comm_events = None
         model.train()
 
     # -- schedule (MultiStepLR stepped once per epoch, train.py:53-56) -----------------------------
@@ -191,9 +194,22 @@ class TrainStep:
 
     def _eager(self, img, label, target, tw):
         self._fwd_bwd(img, label, target, tw)
-        self._sync_grads()
+        if self.comm_events is not None and img.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._sync_grads()
+            e1.record()
+            self.comm_events.append((e0, e1))
+        else:
+            self._sync_grads()
         self._update()
         return self.eng.losses
+
+    def comm_exposed_ms(self):
+        """Mean time per step the compute stream spent waiting for the gradient all-reduce (needs
+        ``comm_events = []`` before the steps and a device synchronisation after them)."""
+        ev = self.comm_events or []
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else 0.0
 
     def _capture(self, img, label, target, tw):
         """Warm up once eagerly (lazy kernel attributes, allocator), capture, then restore every piece

@@ -43,6 +43,9 @@ class Backend:
 
 BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 DTYPES = [pytest.param(torch.float32, id="f32"), pytest.param(torch.bfloat16, id="bf16")]
+# GEMM-shaped kernels also run fp32 tensors in split-bf16 mode (MTN_DTYPE_F32X3): the `x3` marker makes
+# conftest's autouse fixture select it in ops for the duration of the test
+GEMM_DTYPES = DTYPES + [pytest.param(torch.float32, id="x3", marks=pytest.mark.x3)]
 
 
 @pytest.fixture(params=BACKENDS)

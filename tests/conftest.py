@@ -11,6 +11,17 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "x3: fp32 tensors multiplied in split-bf16 mode (MTN_DTYPE_F32X3)")
+
+
+@pytest.fixture(autouse=True)
+def _f32_matmul_mode(request):
+    """ops' fp32 matmul mode is process state (it cannot be read off an fp32 tensor): exact-f32 MFMA for
+    every test except those marked x3, and never leaked from one test into the next."""
+    from hand_gesture_recognition_amd import ops
+    ops.set_f32_matmul(ops.F32X3 if request.node.get_closest_marker("x3") is not None else ops.F32)
+    yield
+    ops.set_f32_matmul(ops.F32)
 
 
 @pytest.fixture(scope="session")

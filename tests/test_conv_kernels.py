@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import DTYPES, be, rel_err, tol  # noqa: F401
+from backend import GEMM_DTYPES as DTYPES, be, rel_err, tol  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
