@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary (include/mtn.h): argument checks, error text, dispatch.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include "mtn.h"
 #include "mtn_kernels.h"
 
@@ -92,6 +93,13 @@ int mtn_conv_dgrad_bn_tiles(int dtype, int B, int H, int W, int Cin, int Cout, i
     return mtn_igemm_stats_tiles(p, dtype);
 }
 
+// BatchNorm-backward hand-over: mtn_conv_dgrad_bn leaves `tiles` rows of (sum dz, sum dz*xhat) in bn_partial and the
+// next mtn_bn_act_bwd on this thread consumes them instead of reducing (dout, y) itself.  The consumer cannot see
+// what the producer wrote, so the producer records it (per thread: the two calls are consecutive steps of one
+// backward pass) and the consumer requires its partial_rows / slab / channel count to match that record.
+struct BnHandover { const float* partial; int tiles; int C; int dtype; };
+static thread_local BnHandover g_handover = {nullptr, 0, 0, 0};
+
 int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res, int ldres,
                       const void* bn_y, int bn_ldy, const void* bn_res, int bn_ldres, const float* bn_scale_shift,
                       const float* bn_mean_rstd, int bn_act, float* bn_partial, int bn_tiles, int dtype, int B, int H,
@@ -105,7 +113,10 @@ int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int ld
     p.bn_y = bn_y; p.bn_ldy = bn_ldy; p.bn_res = bn_res; p.bn_ldr = bn_ldres;
     p.bn_ss = bn_scale_shift; p.bn_mr = bn_mean_rstd; p.bn_act = bn_act;
     p.stats = bn_partial; p.stats_rows = bn_tiles;
-    return mtn_igemm_run(p, dtype, (hipStream_t)stream);
+    g_handover = {nullptr, 0, 0, 0};
+    const int rc2 = mtn_igemm_run(p, dtype, (hipStream_t)stream);
+    if (rc2 == MTN_OK) g_handover = {bn_partial, bn_tiles, Cin, mtn_storage_dtype(dtype)};
+    return rc2;
 }
 
 int mtn_linear_fwd(const void* x, int ldx, const void* w, const float* bias, int act, void* aux_out,
@@ -246,6 +257,15 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
                    float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
                    const void* extra, int ldextra, int partial_rows, int dtype, int M, int C, int act, void* stream) {
     BnBwdArgs a{};
+    if (partial_rows > 0) {
+        const BnHandover h = g_handover;
+        g_handover = {nullptr, 0, 0, 0};                // consumed (or refused) exactly once
+        MTN_REQUIRE(h.partial != nullptr, "bn_act_bwd: partial_rows=%d but no mtn_conv_dgrad_bn launch on this thread left "
+                    "BatchNorm-backward sums (or they were already consumed)", partial_rows);
+        MTN_REQUIRE(h.partial == partial && h.tiles == partial_rows && h.C == C && h.dtype == mtn_storage_dtype(dtype),
+                    "bn_act_bwd: partial_rows=%d rows of %d channels do not match what the preceding mtn_conv_dgrad_bn "
+                    "wrote (%d rows of %d channels%s)", partial_rows, C, h.tiles, h.C, h.partial == partial ? "" : ", another slab");
+    }
     a.partial_rows = partial_rows;
     a.dout = dout; a.lddo = lddo; a.y = y; a.ldy = ldy; a.res = res; a.ldr = ldres;
     a.scale_shift = scale_shift; a.mean_rstd = mean_rstd; a.partial = partial; a.coef = coef;
@@ -344,7 +364,25 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
     return mtn_normalize_image_run(img_hwc_u8, out_nchw, B, H, W, (hipStream_t)stream);
 }
 
+// The diagnostic keys below change tile / pipeline choices process-wide.  They exist for A/B measurements and
+// for tests that must drive every kernel variant; a product process never sets them, and so that "never" is a
+// property of the library and not of its callers, they are refused unless the process opted in through its
+// environment BEFORE the first call (read once): without MTN_ALLOW_DEBUG_KEYS=1 the launch heuristics are
+// immutable for the life of the process (no mutable globals behind the C ABI).
+static bool debug_keys_allowed() {
+    static const bool ok = [] {
+        const char* e = std::getenv("MTN_ALLOW_DEBUG_KEYS");
+        return e != nullptr && e[0] == '1';
+    }();
+    return ok;
+}
+
 int mtn_debug_set(int key, int value) {
+    if (!debug_keys_allowed()) {
+        mtn_set_error("debug_set: diagnostic keys are disabled in this process (set MTN_ALLOW_DEBUG_KEYS=1 in the environment "
+                      "before the first call); the product path has no mutable configuration");
+        return MTN_ERR_UNSUPPORTED;
+    }
     if (key == 1) { mtn_wgrad_set_tr16(value); return MTN_OK; }
     if (key == 2) { mtn_pose_set_dbg(value); return MTN_OK; }
     if (key == 3) { mtn_igemm_set_stages(value); return MTN_OK; }

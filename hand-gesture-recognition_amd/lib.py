@@ -91,6 +91,8 @@ def _bind(path):
             f"{path} not found: the HIP extension is not built. Run `python -c 'import "
             f"__graft_entry__ as g; g.build()'` (or `make -C hand-gesture-recognition_amd/csrc hip`). "
             "There is no CPU fallback.")
+    if os.environ.get("MTN_DEBUG_KEYS"):                 # an A/B run that sets keys opts in to them (capi.hip: mtn_debug_set)
+        os.environ["MTN_ALLOW_DEBUG_KEYS"] = "1"
     lib = C.CDLL(path)
     lib.mtn_last_error.restype = C.c_char_p
     lib.mtn_last_error.argtypes = []

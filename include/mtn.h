@@ -153,7 +153,10 @@ int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void*
  * dres (optional) = gradient of the residual input [+ extra].  partial: f32
  * [mtn_bn_bwd_partial_rows(M)][2][C]; coef: f32 [2][C] scratch.  partial_rows = 0: the sums are
  * reduced here from (dout, y); partial_rows > 0: partial already holds that many rows of them
- * (mtn_conv_dgrad_bn wrote dout and the sums; the slab has mtn_slab_rows(partial_rows) rows). */
+ * (mtn_conv_dgrad_bn wrote dout and the sums; the slab has mtn_slab_rows(partial_rows) rows).
+ * The library records what the last mtn_conv_dgrad_bn on the calling thread wrote (slab, rows, channels)
+ * and REFUSES a partial_rows > 0 call whose slab / rows / C differ from that record or that follows no
+ * such launch; a record is consumed by the first mtn_bn_act_bwd(partial_rows > 0) after it. */
 int mtn_bn_bwd_partial_rows(int M);
 int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
                    const float* scale_shift, const float* mean_rstd, float* partial, float* coef,

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the kernel tests drive every tile / pipeline variant through mtn_debug_set; the library refuses those keys
+# unless the process opted in before its first call (product processes never do)
+os.environ["MTN_ALLOW_DEBUG_KEYS"] = "1"
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -42,3 +42,19 @@ def test_binding_refuses_a_library_with_another_abi_number(monkeypatch):
         lib._bind(path)
     with pytest.raises(RuntimeError, match="ksize"):
         lib.call("mtn_conv_fwd", 0, 0, 0, 0, 0, 0, 0, 0, 1, 8, 8, 64, 64, 5, 1, 0)   # argument check, no launch
+
+
+def test_debug_keys_are_refused_without_opt_in():
+    """The launch heuristics are immutable in a process that did not set MTN_ALLOW_DEBUG_KEYS=1 (VERDICT round 2:
+    no mutable globals behind the C ABI in the product path)."""
+    import subprocess
+    import sys
+    emu = os.path.join(ROOT, "hand-gesture-recognition_amd", "libmtn_emu.so")
+    code = ("import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); l.mtn_last_error.restype = ctypes.c_char_p; "
+            "rc = l.mtn_debug_set(6, 1); print(rc, l.mtn_last_error().decode())")
+    env = {k: v for k, v in os.environ.items() if k not in ("MTN_ALLOW_DEBUG_KEYS", "MTN_DEBUG_KEYS")}
+    out = subprocess.run([sys.executable, "-c", code, emu], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.startswith("3 ") and "disabled" in out, out
+    out = subprocess.run([sys.executable, "-c", code, emu], env=dict(env, MTN_ALLOW_DEBUG_KEYS="1"), capture_output=True,
+                         text=True, check=True).stdout
+    assert out.startswith("0 "), out

@@ -181,6 +181,42 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
         assert torch.equal(dr1, dr0)
 
 
+def test_bn_act_bwd_refuses_a_handover_it_cannot_verify(be):
+    """mtn_bn_act_bwd(partial_rows > 0) trusts rows a preceding mtn_conv_dgrad_bn wrote.  The library
+    records that launch (slab, rows, channels) and refuses a count / slab that does not match it, a hand-over
+    consumed twice, and one that no launch produced."""
+    B, H, W, Cin, Cout, k, s = 2, 6, 6, 64, 64, 3, 1
+    d, dtype = be.device, torch.float32
+    wt = (_rand((Cout, Cin, k, k), dtype, 1) / 24).permute(1, 2, 3, 0).contiguous().to(d)
+    dy, y = _rand((B, H, W, Cout), dtype, 2).to(d), _rand((B, H, W, Cin), dtype, 3).to(d)
+    ss, mr = torch.ones(2, Cin, device=d), torch.ones(2, Cin, device=d)
+    tiles = ops.conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, k, s)
+    part = torch.zeros(ops.slab_rows(tiles) + 8, 2, Cin, device=d)
+    dx = torch.empty((B, H, W, Cin), device=d)
+    coef, dg, db, dyo = torch.empty(2, Cin, device=d), torch.empty(Cin, device=d), torch.empty(Cin, device=d), torch.empty_like(dx)
+
+    def produce():
+        ops.conv_dgrad(dy, wt, dx, None, k, s, bn=(y, None, ss, mr, ops.ACT_SILU, part, tiles))
+
+    def consume(rows, slab=part):
+        ops.bn_act_bwd(dx, y, None, ss, mr, slab, coef, dg, db, dyo, ops.ACT_SILU, partial_rows=rows)
+
+    produce()
+    with pytest.raises(RuntimeError, match="do not match"):
+        consume(tiles + 1)                            # another row count than the producer wrote
+    with pytest.raises(RuntimeError, match="no mtn_conv_dgrad_bn"):
+        consume(tiles)                                # the refused call consumed the record
+    produce()
+    with pytest.raises(RuntimeError, match="another slab"):
+        consume(tiles, torch.zeros_like(part))
+    produce()
+    consume(tiles)                                    # the matching call works ...
+    with pytest.raises(RuntimeError, match="no mtn_conv_dgrad_bn"):
+        consume(tiles)                                # ... once
+    consume(0)                                        # the two-pass form needs no hand-over
+    be.sync()
+
+
 def test_conv_dgrad_bn_refuses_bad_operands(be):
     """Argument errors of the fused hand-over entry fail the call (no launch): a slab sized for another tile
     count, a missing BatchNorm operand, a residual on a unit without activation."""

@@ -149,3 +149,55 @@ def test_odd_batch_sizes_bf16_vs_fp32(B):
     assert abs(float(g16.norm()) / float(m32.flat_grads.norm()) - 1) < 5e-2
     s16._fwd_bwd(*batch)
     assert torch.equal(m16.flat_grads, g16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("keys", [(), ((15, 0),), ((16, 3),)], ids=["default", "parity_major_igemm", "image_tiles"])
+@pytest.mark.parametrize("B", [5, 33])
+def test_bn_backward_handover_equals_two_pass_on_ragged_batches(B, keys, dtype):
+    """the data-gradient epilogues (igemm.hip / dgrad2.hip) pre-reduce the BatchNorm backward of 15
+    of the 21 units.  At batch sizes whose last tiles are partial, EVERY parameter gradient of a whole backward
+    with the hand-over equals the two-pass backward (own reduce pass per unit) -- also through igemm's parity-major
+    rows (key 15 = 0) and with the image tiles forced (key 16 = 3)."""
+    from hand_gesture_recognition_amd import lib
+    be, _, model = _model(192, dtype, seed=3)
+    batch = synthetic_batch(B, (192, 192), 21, 19, be.device, 5)
+    try:
+        for k, v in keys:
+            lib.call("mtn_debug_set", k, v)
+        step = TrainStep(model, B, lr=1e-3)
+        grads = []
+        for fuse in (True, False):
+            step.eng.fuse_bn_bwd = fuse
+            step._fwd_bwd(*batch)
+            be.sync()
+            grads.append({k: p._mtn_grad.clone() for k, p in model.named_parameters()})
+    finally:
+        for k, _ in keys:
+            lib.call("mtn_debug_set", k, 1)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2        # same dz values, f32 sums in another order / from bf16-rounded dx
+    worst = max((rel_err(grads[0][k], grads[1][k]), k) for k in grads[0])
+    assert worst[0] < tol, worst
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), ("bf16x3", 2.5e-3)], ids=["f32", "x3"])
+@pytest.mark.parametrize("kind", ["offset", "unit_interval"])
+def test_stem_backward_with_dc_offset_inputs(kind, dtype, tol):
+    """the fused stem backward forms dW from differences of global sums (conv1.hip); with images
+    that carry a DC offset (un-normalised inputs) those sums nearly cancel.  Whole-model parity against the
+    oracle on x = 2 + 0.3 randn and on x in [0, 1]: stem gradients stay inside the mode's tolerance."""
+    be, sd, model = _model(192, dtype, seed=5)
+    img, label, target, tw = O.synthetic_batch(4, 192, seed=21)
+    g = torch.Generator().manual_seed(77)
+    img = 2.0 + 0.3 * torch.randn(img.shape, generator=g) if kind == "offset" else torch.rand(img.shape, generator=g)
+    batch = (img, label, target, tw)
+    cls_out, hmap, _ = model(img.to(be.device))
+    total, _, _ = O.total_loss(cls_out, hmap, *(t.to(be.device) for t in batch[1:]))
+    total.backward()
+    ref, _, grads = O.forward_backward({k: v.clone() for k, v in sd.items()}, batch)
+    assert rel_err(cls_out, ref[0]) < 1e-3 and rel_err(hmap, ref[1]) < 1e-3
+    stem = {k: rel_err(p.grad, grads[k]) for k, p in model.named_parameters() if k.startswith("encoder.conv1")}
+    worst = max((rel_err(p.grad, grads[k]), k) for k, p in model.named_parameters())
+    print(f"[{kind}/{dtype}] stem {stem}, worst {worst}")
+    assert max(stem.values()) < tol, stem
+    assert worst[0] < 2.5 * tol, worst

@@ -49,7 +49,7 @@ def _check(model, outs, losses, ref_outs, ref_losses, ref_grads, mode, prefix=""
         e = rel_err(o, r)
         assert e < b_out, (mode, n, e)
     for n, l, r in zip(("total", "class", "joints"), losses, ref_losses):
-        e = abs(float(l) - float(r)) / abs(float(r))
+        e = abs(float(l.detach()) - float(r)) / abs(float(r))
         assert e < b_out, (mode, n + " loss", e)
     worst = {"backbone": (0.0, ""), "vit": (0.0, "")}
     for k, p in model.named_parameters():

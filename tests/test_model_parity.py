@@ -1,8 +1,12 @@
 """End-to-end parity of the HIP MultiTaskNet against the oracle / the reference's golden vectors.
 
-fp32 validation mode is held to 1e-3 (max-norm relative) as BASELINE.json's north_star states;
-bf16 throughput mode to the separately stated 5e-2 (the reference itself
-drifts 0.4-2.5e-2 when run in bf16).
+fp32 validation mode is held to 1e-3 (max-norm relative) as BASELINE.json's north_star states, outputs AND
+gradients; the split-bf16 mode "bf16x3" (fp32 storage, three bf16 MFMAs per product) to 1e-3 on outputs, losses
+and BatchNorm statistics and -- at B=4, where the reference's own fp32 gradients are 8.2e-4 away from a float64
+evaluation of the same network (profiles/r03_grad_errors_f64_b4.txt) -- to 2.5e-3 on gradients (1e-3 at the full
+B=256: tests/test_full_size_parity.py); bf16 throughput mode to the separately stated 5e-2 on outputs
+(the reference itself drifts 0.4-2.5e-2 when run in bf16) and per-family gradient bounds
+from the committed per-tensor table (profiles/r03_grad_errors_f64_b4.txt: backbone 8.3e-2, ViT 7.1e-3 worst).
 """
 import os
 
@@ -48,12 +52,17 @@ def _run(be, name, golden_dir, dtype, tol_out, tol_grad):
     assert all(int(msd[k]) == 1 for k in msd if k.endswith("num_batches_tracked"))
     # gradients: every parameter against the oracle (which is pinned to the reference)
     (_, _, _), _, grads = O.forward_backward({k: v.clone() for k, v in sd.items()}, batch)
-    worst = ("", 0.0)
+    # tol_grad: one bound, or {"backbone": conv weights + BatchNorm affine + projection, "vit": everything else}
+    bounds = tol_grad if isinstance(tol_grad, dict) else {"backbone": tol_grad, "vit": tol_grad}
+    worst = {"backbone": ("", 0.0), "vit": ("", 0.0)}
     for k, p in model.named_parameters():
         e = rel_err(p.grad, grads[k])
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < tol_grad, worst
+        f = "backbone" if k.startswith(("encoder", "proj")) else "vit"
+        if e > worst[f][1]:
+            worst[f] = (k, e)
+    for f, (k, e) in worst.items():
+        assert e < bounds[f], (f, k, e)
+    tol_grad = max(bounds.values())
     for k in g.files:
         if k.startswith("grad."):
             assert rel_err(dict(model.named_parameters())[k[5:]].grad, torch.from_numpy(g[k])) < tol_grad, k
@@ -67,6 +76,12 @@ def test_tiny_fp32_emu(golden_dir):
 
 def test_tiny_bf16_emu(golden_dir):
     _run(Backend("emu"), "tiny_b3_s32", golden_dir, torch.bfloat16, 5e-2, 0.25)
+
+
+def test_tiny_bf16x3_emu(golden_dir):
+    """Split-bf16 products through the whole plan on the CPU executor.  Outputs at 1e-3; the gradients of this
+    B=3, 32x32 case (BatchNorm over 12 samples in stage 3) amplify the 2^-17 product error to ~1e-2."""
+    _run(Backend("emu"), "tiny_b3_s32", golden_dir, "bf16x3", 1e-3, 3e-2)
 
 
 @pytest.mark.gpu
@@ -117,9 +132,24 @@ def test_config1_fp32_gpu(golden_dir):
     _run(Backend("hip"), "config1_b4_s192", golden_dir, torch.float32, 1e-3, 1e-3)
 
 
+BF16_GRAD_BOUNDS = {"backbone": 0.15, "vit": 1.5e-2}     # observed at config 1: 8.3e-2 / 7.1e-3 (per-tensor table in profiles/)
+
+
 @pytest.mark.gpu
 def test_config1_bf16_gpu(golden_dir):
-    _run(Backend("hip"), "config1_b4_s192", golden_dir, torch.bfloat16, 5e-2, 0.3)
+    _run(Backend("hip"), "config1_b4_s192", golden_dir, torch.bfloat16, 5e-2, BF16_GRAD_BOUNDS)
+
+
+@pytest.mark.gpu
+def test_config1_bf16x3_gpu(golden_dir):
+    """BASELINE config 1 in the split-bf16 mode: outputs, losses, BN statistics at the north-star 1e-3 (observed
+    2e-5); gradients at 2.5e-3 (observed 1.6e-3 worst; the fp32 reference itself: 8.2e-4 from float64)."""
+    _run(Backend("hip"), "config1_b4_s192", golden_dir, "bf16x3", 1e-3, 2.5e-3)
+
+
+@pytest.mark.gpu
+def test_small_bf16x3_gpu(golden_dir):
+    _run(Backend("hip"), "small_b2_s64", golden_dir, "bf16x3", 1e-3, 1e-2)
 
 
 @pytest.mark.gpu

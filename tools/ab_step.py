@@ -2,6 +2,7 @@
 differ by several percent): python tools/ab_step.py [path/to/other/libmtn_hip.so] [--graph] [--key K=V ...]
 Prints the median / min of several timing windows."""
 import sys, os, time, statistics, torch
+os.environ.setdefault("MTN_ALLOW_DEBUG_KEYS", "1")     # diagnostic tool: opts in to mtn_debug_set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hand_gesture_recognition_amd import lib
 args = [a for a in sys.argv[1:] if not a.startswith("--")]

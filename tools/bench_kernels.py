@@ -5,6 +5,7 @@ Prints one line per case: time (HIP events on the launch stream), TFLOP/s, GB/s 
 """
 import argparse
 import os
+os.environ.setdefault("MTN_ALLOW_DEBUG_KEYS", "1")     # diagnostic tool: opts in to mtn_debug_set
 import sys
 
 import torch

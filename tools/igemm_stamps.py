@@ -8,6 +8,7 @@ loop and the epilogue.
 import argparse
 import ctypes
 import os
+os.environ.setdefault("MTN_ALLOW_DEBUG_KEYS", "1")     # diagnostic tool: opts in to mtn_debug_set
 import sys
 
 import numpy as np
