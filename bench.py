@@ -211,7 +211,7 @@ def validation(a, dev, oracle_ref):
             torch.cuda.synchronize()
             errs[mode] = {"logits": float(f"{_rel(c, oc):.2e}"), "heatmaps": float(f"{_rel(h, oh):.2e}"),
                           "attnmap": float(f"{_rel(at, oa):.2e}"),
-                          "total_loss": float(f"{abs(float(tot) - float(ot)) / abs(float(ot)):.2e}"),
+                          "total_loss": float(f"{abs(float(tot.detach()) - float(ot)) / abs(float(ot)):.2e}"),
                           "worst_param_grad": float(f"{max(_rel(p.grad, og[k]) for k, p in m.named_parameters()):.2e}")}
             del m
         out["errors_vs_oracle_config1_b4"] = errs

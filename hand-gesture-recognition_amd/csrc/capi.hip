@@ -26,7 +26,7 @@ int mtn_check_launch(const char* what) {
 extern "C" {
 
 const char* mtn_last_error(void) { return g_err; }
-int mtn_abi_version(void) { return 3; }
+int mtn_abi_version(void) { return 4; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
@@ -57,6 +57,18 @@ int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float*
     p.A = x; p.Wp = w; p.Out = y; p.lda = ldx; p.ldc = ldy;
     p.stats = stats;
     p.stats_rows = stats_tiles;
+    return mtn_igemm_run(p, dtype, (hipStream_t)stream);
+}
+
+int mtn_conv_bias_act_fwd(const void* x, int ldx, const void* w, const float* bias, int act, const void* res, int ldres,
+                          void* y, int ldy, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                          void* stream) {
+    MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "conv_bias_act_fwd: act=%d", act);
+    IgemmArgs p{};
+    const int rc = conv_fwd_args(p, "conv_bias_act_fwd", B, H, W, Cin, Cout, ksize, stride);
+    if (rc) return rc;
+    p.A = x; p.Wp = w; p.Out = y; p.lda = ldx; p.ldc = ldy;
+    p.bias = bias; p.act = act; p.res = res; p.ldr = ldres;
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
@@ -340,8 +352,9 @@ int mtn_loss_fwd_bwd(const float* logits, const long long* label, const float* h
 int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, float* state, void* stream) {
     return mtn_adamw_run(p, g, m, v, (long)n, state, (hipStream_t)stream);
 }
-int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, void* stream) {
-    return mtn_pack_run(src, dst, desc, ntensors, max_elems, mtn_storage_dtype(dtype), (hipStream_t)stream);
+int mtn_pack_weights(const float* src, const float* scale, void* dst, const int* desc, int ntensors, int max_elems, int dtype,
+                     void* stream) {
+    return mtn_pack_run(src, scale, dst, desc, ntensors, max_elems, mtn_storage_dtype(dtype), (hipStream_t)stream);
 }
 
 int mtn_heatmap_argmax(const float* hm, float* preds, float* maxvals, int maps, int H, int W, void* stream) {

@@ -639,6 +639,9 @@ void igemm_kernel(IgemmArgs p) {
             unpack<T>(*reinterpret_cast<const chunk16*>(gR + (long)m * p.ldr + n0 + ccol), rr);
             MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += rr[e];
         }
+        if (p.act == MTN_ACT_SILU) {                   // inference with folded BatchNorm: SiLU(conv + shift [+ res])
+            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = siluf_(v[e]);
+        }
         const chunk16 o = pack<T>(v);
         *reinterpret_cast<chunk16*>(gO + (long)m * p.ldc + n0 + ccol) = o;
         if (p.stats) {          // statistics of the values exactly as stored

@@ -21,7 +21,8 @@ struct IgemmArgs {
     int mul, sgn, off, div;
     int M, N, K;
     const float* bias;    // [N] or null
-    int act;              // MTN_ACT_NONE / MTN_ACT_GELU / MTN_ACT_GELU_GRAD_ (internal: out *= gelu'(aux), aux_out is READ)
+    int act;              // MTN_ACT_NONE / MTN_ACT_GELU (before res) / MTN_ACT_SILU (AFTER res: folded-BatchNorm inference) /
+                          // MTN_ACT_GELU_GRAD_ (internal: out *= gelu'(aux), aux_out is READ)
     void* aux_out;        // pre-activation copy [M][ld_aux] (GELU backward) or null
     int ld_aux;
     const void* res;      // residual [M][ldr] added after act, or null (may alias Out)
@@ -146,7 +147,7 @@ int mtn_loss_blocks(long n);
 int mtn_loss_run(const float* logits, const long long* label, const float* hm, const float* tgt, const float* tw, float* dlogits,
                  float* dhm, float* partial, float* losses, int B, int C, int J, int HW, float ce_weight, hipStream_t stream);
 int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* state, hipStream_t stream);
-int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream);
+int mtn_pack_run(const float* src, const float* scale, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream);
 int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                     float* scale_shift, int C, hipStream_t stream);
 void mtn_pose_set_dbg(int v);

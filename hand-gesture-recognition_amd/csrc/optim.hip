@@ -47,9 +47,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // desc[t] = {src_off, dst_off, O, I, taps, mode}; mode 0: dst[o][tap][i], mode 1: dst[i][tap][o]; src is OIHW [o][i][tap]
 template <class T>
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, const int* __restrict__ desc) {
-    const int* d = desc + blockIdx.y * 6;
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                   T* __restrict__ dst, const int* __restrict__ desc) {
+    const int* d = desc + blockIdx.y * 7;
     const int so = d[0], dof = d[1], O = d[2], I = d[3], taps = d[4], mode = d[5];
+    // d[6] >= 0: fold a per-output-channel factor scale[d[6] + o] into the weights (inference: the BatchNorm's
+    // gamma / sqrt(running_var + eps), export.py:41-45 runs the model in eval()); forward layout only
+    const float* sc = (d[6] >= 0 && scale != nullptr && mode == 0) ? scale + d[6] : nullptr;
     const int n = O * I * taps;
     if (mode == 1) {
         // dst[i][tap][o] is the TRANSPOSE of the source matrix [O][I*taps]: 64 x 64 tiles through LDS, so
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
         else if (taps == 9) { outer = q / 9; tap = q - outer * 9; }
         else { outer = q / taps; tap = q - outer * taps; }
         const int o = mode == 0 ? outer : f, i = mode == 0 ? f : outer;
-        dst[dof + idx] = from_f<T>(src[so + (o * I + i) * taps + tap]);
+        const float wv = src[so + (o * I + i) * taps + tap];
+        dst[dof + idx] = from_f<T>(sc ? wv * sc[o] : wv);
     }
 }
 
@@ -102,11 +107,11 @@ int mtn_adamw_run(float* p, const float* g, float* m, float* v, long n, float* s
     return mtn_check_launch("adamw");
 }
 
-int mtn_pack_run(const float* src, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream) {
+int mtn_pack_run(const float* src, const float* scale, void* dst, const int* desc, int ntensors, int max_elems, int dtype, hipStream_t stream) {
     MTN_REQUIRE(ntensors > 0 && max_elems > 0, "pack: bad sizes");
     int bx = (max_elems + 255) / 256;
     if (bx > 256) bx = 256;
-    if (dtype == MTN_BF16) MTN_LAUNCH(pack_kernel<bf16_t>, dim3(bx, ntensors), dim3(256), 0, stream, src, (bf16_t*)dst, desc);
-    else MTN_LAUNCH(pack_kernel<float>, dim3(bx, ntensors), dim3(256), 0, stream, src, (float*)dst, desc);
+    if (dtype == MTN_BF16) MTN_LAUNCH(pack_kernel<bf16_t>, dim3(bx, ntensors), dim3(256), 0, stream, src, scale, (bf16_t*)dst, desc);
+    else MTN_LAUNCH(pack_kernel<float>, dim3(bx, ntensors), dim3(256), 0, stream, src, scale, (float*)dst, desc);
     return mtn_check_launch("pack");
 }

@@ -121,7 +121,7 @@ class Engine:
         def add_pack(p, O, I, taps, mode):
             nonlocal off
             src = (p.data_ptr() - flat.data_ptr()) // 4
-            desc.append([src, off, O, I, taps, mode])
+            desc.append([src, off, O, I, taps, mode, -1])
             o = off
             off += O * I * taps
             off = (off + 7) & ~7           # keep every packed tensor 16-byte aligned
@@ -131,6 +131,7 @@ class Engine:
         for u in units:
             wgt = u.mod.weight if isinstance(u.mod, torch.nn.Conv2d) else u.mod.conv.weight
             u.weight = wgt
+            u.pk_row = len(desc)                     # row of the forward-layout entry in the pack table
             u.pk_f = add_pack(wgt, u.cout, u.cin, u.k * u.k, 0)
             u.pk_d = add_pack(wgt, u.cout, u.cin, u.k * u.k, 1) if u is not self.u_conv1 else None
             packs.append(u)
@@ -144,6 +145,20 @@ class Engine:
             self.layers.append(L)
         self.wpack = self._new((off,))
         self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=self.dev)
+        # BatchNorm scale / shift of every unit in ONE buffer ([2][C] per unit): in eval() the pack launch folds the
+        # scale half into the forward weights (second descriptor table) and the shift half is the conv's bias
+        fold_off, foff = {}, 0
+        for u in units:
+            if u.bn:
+                fold_off[id(u)] = foff
+                foff += 2 * u.cout
+        self.fold = self._f32(max(foff, 4))
+        desc_eval = [list(d) for d in desc]
+        for u in units:
+            if u.bn and u is not self.u_conv1:       # (the stem applies scale / shift itself: conv1_bn_act)
+                desc_eval[u.pk_row][6] = fold_off[id(u)]
+        self.pack_desc_eval = torch.tensor(desc_eval, dtype=torch.int32, device=self.dev)
+        self._fold_off = fold_off
         self.pack_n, self.pack_max = len(desc), max(d[2] * d[3] * d[4] for d in desc)
 
         def pview(t):
@@ -170,7 +185,9 @@ class Engine:
                 tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_fwd_stats_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
                 u.tiles = tiles
                 u.stats = self._f32(ops.slab_rows(tiles), 2, u.cout)
-                u.ss, u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout), self._f32(2, u.cout)
+                fo = self._fold_off[id(u)]
+                u.ss = self.fold[fo:fo + 2 * u.cout].view(2, u.cout)
+                u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout)
                 if u is not self.u_conv1:
                     max_part = max(max_part, ops.bn_bwd_partial_rows(M) * 2 * u.cout)
             u.pre_rows = 0      # > 0: the data gradient that produced this unit's output gradient left that many rows of BN-backward sums in bn_part
@@ -252,26 +269,42 @@ class Engine:
                                "model.engine(batch) and rebuild the TrainStep")
 
     @_in_plan_mode
-    def pack_weights(self):
+    def pack_weights(self, folded=False):
+        """Refresh the kernels' copy of the weights from the fp32 masters.  ``folded`` (inference): every Conv
+        unit's BatchNorm scale -- its u.ss[0], filled by bn_eval_scale_shift before this call -- is multiplied
+        into its forward weights."""
         self.check_current()
-        ops.pack_weights(self.model.flat_params, self.wpack, self.pack_desc, self.pack_n, self.pack_max)
+        ops.pack_weights(self.model.flat_params, self.wpack, self.pack_desc_eval if folded else self.pack_desc,
+                         self.pack_n, self.pack_max, scale=self.fold if folded else None)
+
+    @_in_plan_mode
+    def fold_batchnorm(self):
+        """eval(): scale / shift of every BatchNorm from its running statistics, then the packed weights with the
+        scale folded in -- after this the forward has no BatchNorm pass at all (export.py:41-45)."""
+        for u in self.units:
+            if u.bn:
+                bn = u.mod.bn
+                ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, u.ss, bn.eps)
+        self.pack_weights(folded=True)
 
     def _dy(self, u):
         return self.dyraw[:u.M * u.cout].view(self.B, u.hout, u.wout, u.cout)
 
-    def _bn_fwd(self, u, out, training, res=None):
+    def _bn_fwd(self, u, out, res=None):
+        """train mode: batch statistics from the conv epilogue's partial sums, then normalise + activation"""
         bn = u.mod.bn
-        if training:
-            ops.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
-        else:
-            ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, u.ss, bn.eps)
+        ops.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                        bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
         ops.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
 
     def _conv(self, u, x, out, training, res=None):
         """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87)"""
-        ops.conv_fwd(x, u.wf, u.raw, u.stats if training else None, u.k, u.s, stats_tiles=u.tiles if u.bn else None)
-        self._bn_fwd(u, out, training, res)
+        if not training:
+            # eval(): BatchNorm folded into the weights (pack_weights(folded=True)) and an epilogue bias: one launch
+            ops.conv_bias_act_fwd(x, u.wf, u.ss[1], out, _ACT[u.act or res is not None], u.k, u.s, res=res)
+            return
+        ops.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles)
+        self._bn_fwd(u, out, res)
 
     def _dgrad(self, u, dy, g_in, g_in_res=None, nxt=None):
         """g_in = data gradient of unit ``u`` [+ g_in_res].  ``nxt`` = (unit, its residual input or None) when
@@ -303,15 +336,15 @@ class Engine:
     # ---------------------------------------------------------------- forward
     @_in_plan_mode
     def backbone_forward(self, x, training=True):
-        """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512]."""
+        """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512].
+        The packed weights must be current: pack_weights() before a training pass, fold_batchnorm() before an
+        inference pass (forward() does either)."""
         u1, bn1 = self.u_conv1, self.u_conv1.mod.bn
         self.x_in = x
         if training:
             ops.conv1_stats(x, u1.wf, u1.stats)
             ops.bn_finalize(u1.stats, u1.tiles, u1.M, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                             bn1.num_batches_tracked, u1.ss, u1.mr, bn1.momentum, bn1.eps)
-        else:
-            ops.bn_eval_scale_shift(bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, u1.ss, bn1.eps)
         ops.conv1_bn_act(x, u1.wf, u1.ss, self.a1, _ACT[u1.act])
         self._conv(self.u_conv2, self.a1, self.a2, training)
         cur = self.a2
@@ -338,7 +371,10 @@ class Engine:
     def forward(self, x, training=True, want_attn=True):
         """MultiTaskNet.forward (model/multitasknet.py:24-29) -> (logits, heatmaps, attnmap)."""
         assert tuple(x.shape) == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
-        self.pack_weights()
+        if training:
+            self.pack_weights()
+        else:
+            self.fold_batchnorm()
         feats = self.backbone_forward(x, training)
         up = self.u_proj
         ops.conv_fwd(feats, up.wf, up.raw, None, 1, 1)                                   # multitasknet.py:26

@@ -62,7 +62,8 @@ _PROTOS = {
     "mtn_loss_partial_len": [_ll],
     "mtn_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mtn_adamw_step": [_vp, _vp, _vp, _vp, _ll, _vp, _vp],
-    "mtn_pack_weights": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_pack_weights": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mtn_conv_bias_act_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_heatmap_argmax": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_pose_accuracy": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mtn_cls_confusion": [_vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -79,7 +80,7 @@ _STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_ti
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",
                 "mtn_loss_partial_len"}   # return a value, not a status
 
-EXPECTED_ABI = 3          # include/mtn.h MTN_ABI_VERSION these prototypes were written for
+EXPECTED_ABI = 4          # include/mtn.h MTN_ABI_VERSION these prototypes were written for
 
 _lib = None
 _lib_path = None

@@ -83,6 +83,20 @@ def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
              B, H, W, Cin, Cout, ksize, stride, _stream(x))
 
 
+def conv_bias_act_fwd(x, w, bias, y, act, ksize, stride, res=None):
+    """Inference form of a Conv unit with folded BatchNorm: y = act(conv(x) + bias [+ res]) in one launch
+    (w = weights packed with the BatchNorm scale, bias f32 [Cout] = its shift)."""
+    B, H, W, Cin = x.shape
+    Cout = y.shape[-1]
+    if bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous():
+        raise ValueError("conv_bias_act_fwd: bias must be a contiguous f32 [Cout] tensor")
+    xp, ldx = _rows(x)
+    yp, ldy = _rows(y)
+    rp, ldr = _rows(res) if res is not None else (0, 0)
+    lib.call("mtn_conv_bias_act_fwd", xp, ldx, w.data_ptr(), bias.data_ptr(), act, rp, ldr, yp, ldy, dtype_code(x),
+             B, H, W, Cin, Cout, ksize, stride, _stream(x))
+
+
 def conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
     return lib.call("mtn_conv_dgrad_bn_tiles", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
 
@@ -407,6 +421,9 @@ def adamw_step(p, g, m, v, state):
              state.data_ptr(), _stream(p))
 
 
-def pack_weights(src, dst, desc, ntensors, max_elems):
-    lib.call("mtn_pack_weights", src.data_ptr(), dst.data_ptr(), desc.data_ptr(), ntensors, max_elems,
+def pack_weights(src, dst, desc, ntensors, max_elems, scale=None):
+    """desc int32 [ntensors][7] (include/mtn.h); ``scale``: f32 buffer the rows' scale_off index into."""
+    if desc.dtype != torch.int32 or desc.numel() != ntensors * 7:
+        raise ValueError("pack_weights: desc must be int32 [ntensors][7]")
+    lib.call("mtn_pack_weights", src.data_ptr(), _p(scale), dst.data_ptr(), desc.data_ptr(), ntensors, max_elems,
              dtype_code(dst), _stream(dst))

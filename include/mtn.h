@@ -60,6 +60,13 @@ int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float*
                  int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                  void* stream);
 
+/* Inference form of a Conv unit with its BatchNorm folded away (model/gelan.py:56, 78-87 in eval()):
+ * y = act(conv(x) + bias [+ res]), act in {NONE, SILU}; w = the folded weights (mtn_pack_weights with a
+ * scale), bias f32 [Cout] = beta - running_mean * scale.  One launch per unit, no raw output, no BN pass. */
+int mtn_conv_bias_act_fwd(const void* x, int ldx, const void* w, const float* bias, int act, const void* res,
+                          int ldres, void* y, int ldy, int dtype, int B, int H, int W, int Cin, int Cout,
+                          int ksize, int stride, void* stream);
+
 /* dx = conv_transpose(dy) [+ res]; wt packed [Cin][k][k][Cout]; (H, W) is the INPUT size. */
 int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
                    const void* res, int ldres, int dtype, int B, int H, int W, int Cin, int Cout,
@@ -236,10 +243,14 @@ int mtn_loss_fwd_bwd(const float* logits, const long long* label, const float* h
  * state f32[16]: lr, beta1, beta2, eps, weight_decay, step, bias_corr1, bias_corr2, grad_scale.
  * One call = step += 1, bias corrections, decoupled decay and the Adam update over n elements. */
 int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, float* state, void* stream);
-/* repack fp32 master weights (OIHW) into kernel operand layouts; desc int32 [ntensors][6] =
- * {src_off, dst_off, O, I, taps, mode}; mode 0: [O][tap][I] (forward), 1: [I][tap][O] (dgrad). */
-int mtn_pack_weights(const float* src, void* dst, const int* desc, int ntensors, int max_elems,
-                     int dtype, void* stream);
+/* repack fp32 master weights (OIHW) into kernel operand layouts; desc int32 [ntensors][7] =
+ * {src_off, dst_off, O, I, taps, mode, scale_off}; mode 0: [O][tap][I] (forward), 1: [I][tap][O] (dgrad).
+ * scale_off >= 0 (mode 0 only, scale != NULL): the weights of output channel o are multiplied by
+ * scale[scale_off + o] -- inference with BatchNorm folded into the convolution (the reference runs its
+ * model in eval() for export / evaluation, export.py:41-45): scale = gamma / sqrt(running_var + eps) from
+ * mtn_bn_eval_scale_shift, the matching shift goes to mtn_conv_bias_act_fwd as its bias.  -1: no factor. */
+int mtn_pack_weights(const float* src, const float* scale, void* dst, const int* desc, int ntensors,
+                     int max_elems, int dtype, void* stream);
 
 /* ---- step metrics on the device (reference: host numpy / sklearn per step) ------
  * get_max_preds (libs/utils.py:4-32): preds f32 [maps][2] = (x, y) of the first maximum, zeroed

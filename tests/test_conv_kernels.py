@@ -472,15 +472,30 @@ def test_pack_weights_layouts(be, dtype):
     for w in ws:
         O, I, kh, kw = w.shape
         for mode in (0, 1):
-            desc.append([src, off, O, I, kh * kw, mode])
+            desc.append([src, off, O, I, kh * kw, mode, -1])
             off = (off + w.numel() + 7) & ~7
         src += w.numel()
     dst = torch.full((off,), float("nan"), dtype=dtype, device=be.device)
-    ops.pack_weights(flat.to(be.device), dst, torch.tensor(desc, dtype=torch.int32, device=be.device), len(desc),
-                     max(w.numel() for w in ws))
+    dd = torch.tensor(desc, dtype=torch.int32, device=be.device)
+    ops.pack_weights(flat.to(be.device), dst, dd, len(desc), max(w.numel() for w in ws))
     be.sync()
     for j, w in enumerate(ws):
         for mode in (0, 1):
             o = desc[2 * j + mode][1]
             want = (pack_krsc if mode == 0 else pack_crsk)(w, dtype).flatten()
             assert torch.equal(dst[o:o + w.numel()].cpu(), want), (j, mode)
+    # folded form (inference): the forward layout of tensors 1 and 3 multiplied by a per-output-channel factor
+    scale = 0.5 + torch.rand(400, generator=torch.Generator().manual_seed(9))
+    for j, so in ((1, 7), (3, 140)):
+        desc[2 * j][6] = so
+    dst2 = torch.full((off,), float("nan"), dtype=dtype, device=be.device)
+    ops.pack_weights(flat.to(be.device), dst2, torch.tensor(desc, dtype=torch.int32, device=be.device), len(desc),
+                     max(w.numel() for w in ws), scale=scale.to(be.device))
+    be.sync()
+    for j, w in enumerate(ws):
+        for mode in (0, 1):
+            o = desc[2 * j + mode][1]
+            so = desc[2 * j + mode][6]
+            wf = w * scale[so:so + w.shape[0]].view(-1, 1, 1, 1) if (so >= 0 and mode == 0) else w
+            want = (pack_krsc if mode == 0 else pack_crsk)(wf, dtype).flatten()
+            assert torch.equal(dst2[o:o + w.numel()].cpu(), want), (j, mode, "folded")

@@ -204,6 +204,56 @@ def test_train_steps_graph_gpu(golden_dir):
     _train_steps(Backend("hip"), "small_b2_s64", golden_dir, torch.float32, 3, 2e-3, use_graph=True)
 
 
+def _eval_case(be, dtype, tol):
+    """model.eval() with non-trivial running statistics against the oracle in eval mode; the forward must not run
+    a single BatchNorm pass (the statistics are folded into the packed weights, the shift is the conv's bias)."""
+    from hand_gesture_recognition_amd import ops
+    sd = O.synthetic_state_dict(21, 19, seed=2)
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = 0.3 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    S = 32 if be.name == "emu" else 192
+    batch = O.synthetic_batch(2 if be.name == "emu" else 4, S, seed=11)
+    ref = O.multitasknet_forward(batch[0], {k: v.clone() for k, v in sd.items()}, training=False)
+    model = MultiTaskNet(21, 19, [S, S], compute_dtype=dtype)
+    model.load_state_dict(sd, strict=True)
+    model.to(be.device).eval()
+    saved = (ops.bn_act_fwd, ops.bn_finalize)
+
+    def no_bn(*a, **k):
+        raise AssertionError("a BatchNorm pass ran in eval mode")
+    ops.bn_act_fwd = ops.bn_finalize = no_bn
+    try:
+        with torch.no_grad():
+            cls_out, hmap, attn = model(batch[0].to(be.device))
+        be.sync()
+    finally:
+        ops.bn_act_fwd, ops.bn_finalize = saved
+    assert rel_err(cls_out, ref[0]) < tol and rel_err(hmap, ref[1]) < tol and rel_err(attn, ref[2]) < tol
+    msd = model.state_dict()
+    assert all(int(v) == 0 for k, v in msd.items() if k.endswith("num_batches_tracked"))
+    assert all(torch.equal(msd[k].cpu(), sd[k]) for k in sd if "running" in k)          # no state is mutated
+    # a training forward right after re-packs the unfolded weights
+    model.train()
+    c2 = model(batch[0].to(be.device))[0]
+    r2 = O.multitasknet_forward(batch[0], {k: v.clone() for k, v in sd.items()}, training=True)[0]
+    assert rel_err(c2, r2) < max(tol, 2e-2 if dtype == torch.bfloat16 else 0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), ("bf16x3", 1e-3), (torch.bfloat16, 3e-2)], ids=["f32", "x3", "bf16"])
+def test_eval_mode_folded_batchnorm_emu(dtype, tol):
+    _eval_case(Backend("emu"), dtype, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), ("bf16x3", 1e-3), (torch.bfloat16, 3e-2)], ids=["f32", "x3", "bf16"])
+def test_eval_mode_folded_batchnorm_gpu(dtype, tol):
+    _eval_case(Backend("hip"), dtype, tol)
+
+
 @pytest.mark.gpu
 def test_eval_mode_gpu(golden_dir):
     """model.eval(): BatchNorm uses running statistics (export.py:41), no state is mutated."""

@@ -279,7 +279,7 @@ def test_adamw_and_pack(be):
     assert rel_err(pd, sd["w"]) < 1e-5
     # pack: OIHW -> [O][tap][I] and [I][tap][O]
     w = _rand((8, 4, 3, 3), torch.float32, 31).to(d)
-    desc = torch.tensor([[0, 0, 8, 4, 9, 0], [0, 288, 8, 4, 9, 1]], dtype=torch.int32, device=d)
+    desc = torch.tensor([[0, 0, 8, 4, 9, 0, -1], [0, 288, 8, 4, 9, 1, -1]], dtype=torch.int32, device=d)
     for dt in (torch.float32, torch.bfloat16):
         dst = torch.empty(576, dtype=dt, device=d)
         ops.pack_weights(w, dst, desc, 2, 288)
