@@ -26,6 +26,9 @@ constexpr int HD = 32;                       // head_dim (model/multitasknet.py:
 // LDS row pitch: bf16 rows are padded by 16 bytes (conflict-free fragment reads); the fp32
 // validation mode keeps rows unpadded so that K and V of a 577-token head (384x384) still fit.
 template <class T> struct Lay { static constexpr int PITCH = sizeof(T) == 2 ? HD + 8 : HD; };
+// split-bf16 mode: fp32 rows padded by 16 bytes (its fragments are 16-byte reads like the bf16 mode's; sequences whose
+// padded K / V no longer fit LDS run the exact-f32 kernels instead, check below)
+template <> struct Lay<f32x3_t> { static constexpr int PITCH = HD + 4; };
 
 // ---- operand over the head_dim axis of one row (A: [row][k], B: [k][col]) ----------------------
 template <class T> struct RowOp;
@@ -46,6 +49,18 @@ template <> struct RowOp<float> {
         MTN_UNROLL for (int ks = 0; ks < 8; ++ks) f[ks] = valid ? row[ks * 4 + g] : 0.f;
     }
 };
+// fp32 storage, split-bf16 products (Mma<f32x3_t>, mtn_types.h): lane group g holds k = 8g .. 8g+7 of its row
+template <> struct RowOp<f32x3_t> {
+    Frag3 f;
+    __device__ __forceinline__ void load(const f32x3_t* row, bool valid, int g) {
+        const chunk16* q = reinterpret_cast<const chunk16*>(row + 8 * g);
+        const chunk16 c0 = valid ? q[0] : zero_chunk(), c1 = valid ? q[1] : zero_chunk();
+        f = Mma<f32x3_t>::split2(c0, c1);
+    }
+};
+__device__ __forceinline__ f32x4_t mma32(const RowOp<f32x3_t>& a, const RowOp<f32x3_t>& b, f32x4_t c) {
+    return Mma<f32x3_t>::mma(a.f, b.f, c);
+}
 __device__ __forceinline__ f32x4_t mma32(const RowOp<bf16_t>& a, const RowOp<bf16_t>& b, f32x4_t c) {
     return Mma<bf16_t>::mma(a.f, b.f, c);
 }
@@ -57,6 +72,17 @@ template <class T> __device__ __forceinline__ float dot_rowops(const RowOp<T>& a
 template <> __device__ __forceinline__ float dot_rowops<float>(const RowOp<float>& a, const RowOp<float>& b) {
     float s = 0.f;
     MTN_UNROLL for (int i = 0; i < 8; ++i) s += a.f[i] * b.f[i];
+    return s;
+}
+template <> __device__ __forceinline__ float dot_rowops<f32x3_t>(const RowOp<f32x3_t>& a, const RowOp<f32x3_t>& b) {
+    float s = 0.f;
+    MTN_UNROLL for (int i = 0; i < 8; ++i) {
+#ifdef MTN_EMU
+        s += (emu::bf2f(a.f.hi[i]) + emu::bf2f(a.f.lo[i])) * (emu::bf2f(b.f.hi[i]) + emu::bf2f(b.f.lo[i]));
+#else
+        s += ((float)a.f.hi[i] + (float)a.f.lo[i]) * ((float)b.f.hi[i] + (float)b.f.lo[i]);
+#endif
+    }
     return s;
 }
 template <> __device__ __forceinline__ float dot_rowops<bf16_t>(const RowOp<bf16_t>& a, const RowOp<bf16_t>& b) {
@@ -100,14 +126,43 @@ __device__ __forceinline__ f32x4_t acc_mma(const float* col, int pitch, f32x4_t 
     return out;
 }
 
+__device__ __forceinline__ f32x4_t acc_mma(const f32x3_t* col, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const float* c = reinterpret_cast<const float*>(col);
+    float a[8], b[8];
+    MTN_UNROLL for (int j = 0; j < 4; ++j) {
+        a[j] = c[(4 * g + j) * pitch + i];
+        a[4 + j] = c[(16 + 4 * g + j) * pitch + i];
+        b[j] = t0[j];
+        b[4 + j] = t1[j];
+    }
+    return Mma<f32x3_t>::mma(Mma<f32x3_t>::split(a), Mma<f32x3_t>::split(b), out);
+}
+
 // stage rows [0, NP) x 32 of one head (column offset `coff` of a [B*N][ld] tensor) into LDS, zero padded
+// TWO such tiles at once, with all global loads of a batch issued before the first LDS store: staged one 16-byte
+// chunk per loop trip the workgroup paid one full memory round trip per trip (five of them for a 145-token head,
+// ~7 us of a 33 us kernel that moves its bytes in 12); here a batch keeps 2 x 4 loads per thread in flight.
 template <class T>
-__device__ __forceinline__ void stage_head(T* dst, const T* __restrict__ src, int ld, int coff, long row0, int N, int NP) {
-    constexpr int VEC = 16 / (int)sizeof(T), CPR = HD / VEC, PITCH = Lay<T>::PITCH;
-    for (int i = threadIdx.x; i < NP * CPR; i += blockDim.x) {
-        const int r = i / CPR, c = (i - r * CPR) * VEC;
-        *reinterpret_cast<chunk16*>(dst + r * PITCH + c) =
-            (r < N) ? *reinterpret_cast<const chunk16*>(src + (row0 + r) * ld + coff + c) : zero_chunk();
+__device__ __forceinline__ void stage_heads(T* dst0, const T* __restrict__ src0, int ld0, int coff0, T* dst1,
+                                            const T* __restrict__ src1, int ld1, int coff1, long row0, int N, int NP) {
+    constexpr int VEC = 16 / (int)sizeof(T), CPR = HD / VEC, PITCH = Lay<T>::PITCH, NB = 4;
+    const int total = NP * CPR, nt = (int)blockDim.x;
+    for (int base = threadIdx.x; base < total; base += NB * nt) {
+        chunk16 a[NB], b[NB];
+        MTN_UNROLL for (int j = 0; j < NB; ++j) {
+            const int i = base + j * nt, r = i / CPR, c = (i - r * CPR) * VEC;
+            const bool ok = i < total && r < N;
+            a[j] = ok ? *reinterpret_cast<const chunk16*>(src0 + (row0 + r) * ld0 + coff0 + c) : zero_chunk();
+            b[j] = ok ? *reinterpret_cast<const chunk16*>(src1 + (row0 + r) * ld1 + coff1 + c) : zero_chunk();
+        }
+        MTN_UNROLL for (int j = 0; j < NB; ++j) {
+            const int i = base + j * nt, r = i / CPR, c = (i - r * CPR) * VEC;
+            if (i < total) {
+                *reinterpret_cast<chunk16*>(dst0 + r * PITCH + c) = a[j];
+                *reinterpret_cast<chunk16*>(dst1 + r * PITCH + c) = b[j];
+            }
+        }
     }
 }
 
@@ -133,15 +188,30 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
     const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
     const int ld = 3 * H * HD;
     const long row0 = (long)b * N;
-    stage_head<T>(sK, qkv, ld, H * HD + h * HD, row0, N, NP);
-    stage_head<T>(sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    for (int qt = wid; qt < nqt; qt += (int)(blockDim.x >> 6)) {
+    const int nw = (int)(blockDim.x >> 6);
+    // the query fragment of a tile comes straight from global memory: requested one tile ahead (the first one
+    // before the K / V staging), so its latency is not on the tile's critical path
+    RowOp<T> qnext;
+    {
+        const int q = wid * 16 + li;
+        qnext.load(qkv + (row0 + (q < N ? q : 0)) * ld + h * HD, wid < nqt && q < N, g);
+    }
+    stage_heads<T>(sK, qkv, ld, H * HD + h * HD, sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
+    __syncthreads();
+    for (int qt = wid; qt < nqt; qt += nw) {
         const int q = qt * 16 + li;
         const bool qok = q < N;
-        RowOp<T> qf;
-        qf.load(qkv + (row0 + (qok ? q : 0)) * ld + h * HD, qok, g);
+        const RowOp<T> qf = qnext;
+        {
+            const int qn = (qt + nw) * 16 + li;
+            qnext.load(qkv + (row0 + (qn < N ? qn : 0)) * ld + h * HD, qt + nw < nqt && qn < N, g);
+        }
+        // The softmax is the VALU-bound part of this kernel (40 scores per lane and tile against 20 MFMAs), so it is
+        // kept to max / fma / exp2 / add per score: the maximum is taken over the RAW scores (scale > 0), scale and
+        // log2(e) are one factor inside the exponent's fma, only the tiles that hold padded keys are masked (their
+        // -3e38 turns into an exact 0 in exp2, no select), and the 1 / sum normalisation is applied to the 8 output
+        // values of the lane's query instead of its scores (unless the probabilities themselves are returned).
         f32x4_t s[MAXT];
         float mx = -3.0e38f;
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
@@ -149,21 +219,21 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
                 RowOp<T> kf;
                 kf.load(sK + (kt * 16 + li) * PITCH, true, g);
                 s[kt] = mma32(kf, qf, zero4());
-                MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                    const bool kok = kt * 16 + 4 * g + r < N;
-                    s[kt][r] = kok ? s[kt][r] * scale : -3.0e38f;
-                    mx = fmaxf(mx, s[kt][r]);
+                if (kt * 16 + 16 > N) {                    // (wave-uniform) tile with padded keys
+                    MTN_UNROLL for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + 4 * g + r >= N) s[kt][r] = -3.0e38f;
                 }
+                MTN_UNROLL for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float c2 = scale * 1.4426950408889634f, mc = mx * c2;
         float sum = 0.f;
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
             if (kt < nkt) {
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                    const bool kok = kt * 16 + 4 * g + r < N;
-                    const float e = kok ? __expf(s[kt][r] - mx) : 0.f;
+                    const float e = exp2f_(fmaf(s[kt][r], c2, -mc));
                     s[kt][r] = e;
                     sum += e;
                 }
@@ -172,14 +242,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
-        if (qok && g == 0) lse[(long)bh * N + q] = mx + __logf(sum);
-        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
-            if (kt < nkt) {
-                MTN_UNROLL for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-                if (attn && qok) {
+        if (qok && g == 0) lse[(long)bh * N + q] = mx * scale + __logf(sum);
+        if (attn && qok) {
+            MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
+                if (kt < nkt) {
                     float* ap = attn + ((long)bh * N + q) * N + kt * 16 + 4 * g;
                     MTN_UNROLL for (int r = 0; r < 4; ++r)
-                        if (kt * 16 + 4 * g + r < N) ap[r] = s[kt][r];
+                        if (kt * 16 + 4 * g + r < N) ap[r] = s[kt][r] * inv;
                 }
             }
         }
@@ -190,6 +259,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
                 o1 = acc_mma(sV + pr * 32 * PITCH + 16, PITCH, s[2 * pr], s[2 * pr + 1], o1, lane);
             }
         }
+        MTN_UNROLL for (int r = 0; r < 4; ++r) { o0[r] *= inv; o1[r] *= inv; }
         if (qok) {      // O^T tiles: rows d = dt*16 + 4g + r, column q
             T* op = out + (row0 + q) * (H * HD) + h * HD + 4 * g;
             store4<T>(op, o0);
@@ -212,22 +282,31 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
     const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
     const int ld = 3 * H * HD, ldo = H * HD;
     const long row0 = (long)b * N;
-    stage_head<T>(sK, qkv, ld, H * HD + h * HD, row0, N, NP);
-    stage_head<T>(sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    for (int qt = wid; qt < nqt; qt += (int)(blockDim.x >> 6)) {
+    const int nw = (int)(blockDim.x >> 6);
+    RowOp<T> qn_, don_, on_;                              // row operands of the NEXT query tile (requested one tile ahead)
+    auto fetch = [&](int qt) {
+        const int q = qt * 16 + li;
+        const bool ok = qt < nqt && q < N;
+        const long qr = row0 + (ok ? q : 0);
+        qn_.load(qkv + qr * ld + h * HD, ok, g);
+        don_.load(dout + qr * ldo + h * HD, ok, g);
+        on_.load(o + qr * ldo + h * HD, ok, g);
+    };
+    fetch(wid);
+    stage_heads<T>(sK, qkv, ld, H * HD + h * HD, sV, qkv, ld, 2 * H * HD + h * HD, row0, N, NP);
+    __syncthreads();
+    for (int qt = wid; qt < nqt; qt += nw) {
         const int q = qt * 16 + li;
         const bool qok = q < N;
-        const long qr = row0 + (qok ? q : 0);
-        RowOp<T> qf, dof, of;
-        qf.load(qkv + qr * ld + h * HD, qok, g);
-        dof.load(dout + qr * ldo + h * HD, qok, g);
-        of.load(o + qr * ldo + h * HD, qok, g);
+        const RowOp<T> qf = qn_, dof = don_, of = on_;
+        fetch(qt + nw);
         float dl = dot_rowops<T>(dof, of);
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
-        const float lq = qok ? lse[(long)bh * N + q] : 0.f;
+        // only the tiles that hold padded keys are masked (below); padded query lanes compute a column that is never stored
+        const float c2 = scale * 1.4426950408889634f;
+        const float lq2 = (qok ? lse[(long)bh * N + q] : 0.f) * 1.4426950408889634f;
         if (qok && g == 0) delta[(long)bh * N + q] = dl;
         f32x4_t ds[MAXT];
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
@@ -238,9 +317,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
                 const f32x4_t s = mma32(kf, qf, zero4());
                 const f32x4_t dp = mma32(vf, dof, zero4());
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                    const bool ok = qok && (kt * 16 + 4 * g + r < N);
-                    const float p = ok ? __expf(s[r] * scale - lq) : 0.f;
+                    const float p = exp2f_(fmaf(s[r], c2, -lq2));
                     ds[kt][r] = p * (dp[r] - dl) * scale;
+                }
+                if (kt * 16 + 16 > N) {                    // (wave-uniform) tile with padded keys: exp(0 - lse) may overflow
+                    MTN_UNROLL for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + 4 * g + r >= N) ds[kt][r] = 0.f;
                 }
             }
         }
@@ -275,22 +357,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
     const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
     const int ld = 3 * H * HD, ldo = H * HD;
     const long row0 = (long)b * N;
-    stage_head<T>(sQ, qkv, ld, h * HD, row0, N, NP);
-    stage_head<T>(sD, dout, ldo, h * HD, row0, N, NP);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    const int nw = (int)(blockDim.x >> 6);
+    RowOp<T> kn_, vn_;                                    // K^T / V^T operands of the NEXT key tile
+    auto fetch = [&](int kt) {
+        const int key = kt * 16 + li;
+        const bool ok = kt < nkt && key < N;
+        const long kr = row0 + (ok ? key : 0);
+        kn_.load(qkv + kr * ld + H * HD + h * HD, ok, g);
+        vn_.load(qkv + kr * ld + 2 * H * HD + h * HD, ok, g);
+    };
+    fetch(wid);
+    stage_heads<T>(sQ, qkv, ld, h * HD, sD, dout, ldo, h * HD, row0, N, NP);
     if (kStageRows)
         for (int i = threadIdx.x; i < NP; i += blockDim.x) {
             sL[i] = i < N ? lse[(long)bh * N + i] : 0.f;
             sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
         }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    for (int kt = wid; kt < nkt; kt += (int)(blockDim.x >> 6)) {
+    const float c2 = scale * 1.4426950408889634f;
+    for (int kt = wid; kt < nkt; kt += nw) {
         const int key = kt * 16 + li;
         const bool kok = key < N;
-        const long kr = row0 + (kok ? key : 0);
-        RowOp<T> kf, vf;                                  // B operands K^T, V^T: [k = d][col = key]
-        kf.load(qkv + kr * ld + H * HD + h * HD, kok, g);
-        vf.load(qkv + kr * ld + 2 * H * HD + h * HD, kok, g);
+        const RowOp<T> kf = kn_, vf = vn_;                // B operands K^T, V^T: [k = d][col = key]
+        fetch(kt + nw);
         f32x4_t dk0 = zero4(), dk1 = zero4(), dv0 = zero4(), dv1 = zero4();
         for (int qp = 0; qp < nqp; ++qp) {
             f32x4_t p[2], ds[2];
@@ -301,12 +391,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
                 da.load(sD + (qb + li) * PITCH, true, g);
                 const f32x4_t s = mma32(qa, kf, zero4());       // S[q = qb+4g+r][key]
                 const f32x4_t dp = mma32(da, vf, zero4());      // dP[q][key]
+                // (padded queries need no mask: their Q and dO rows are zero in LDS, so they add nothing to
+                //  dV = P^T dO and dK = dS^T Q; padded key lanes compute columns that are never stored)
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
                     const int q = qb + 4 * g + r;
-                    const bool ok = kok && q < N;
                     const float lq = kStageRows ? sL[q] : (q < N ? lse[(long)bh * N + q] : 0.f);
                     const float dq = kStageRows ? sDl[q] : (q < N ? delta[(long)bh * N + q] : 0.f);
-                    const float pv = ok ? __expf(s[r] * scale - lq) : 0.f;
+                    const float pv = exp2f_(fmaf(s[r], c2, -lq * 1.4426950408889634f));
                     p[hf][r] = pv;
                     ds[hf][r] = pv * (dp[r] - dq) * scale;
                 }
@@ -370,6 +461,12 @@ int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
     return mtn_check_launch("attn_bwd_dkv");
 }
 
+// split-bf16 mode where its padded K / V (or Q / dO) tiles fit LDS, exact-f32 kernels (unpadded rows) beyond that
+bool attn_x3_fits(int N) {
+    const int NP = (N + 31) & ~31;
+    return 2 * (size_t)NP * Lay<f32x3_t>::PITCH * sizeof(float) <= 160 * 1024;
+}
+
 int check_attn(const AttnArgs& a, int dtype) {
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "attention: bad dtype");
     MTN_REQUIRE(a.B > 0 && a.H > 0 && a.N > 0 && a.D == HD, "attention: head_dim must be %d (got %d)", HD, a.D);
@@ -383,13 +480,19 @@ int check_attn(const AttnArgs& a, int dtype) {
 }  // namespace
 
 int mtn_attn_fwd_run(const AttnArgs& a, int dtype, hipStream_t stream) {
+    const bool x3 = dtype == MTN_F32X3 && attn_x3_fits(a.N);
+    dtype = mtn_storage_dtype(dtype);
     int rc = check_attn(a, dtype);
     if (rc) return rc;
+    if (x3) return attn_fwd_t<f32x3_t>(a, stream);
     return dtype == MTN_BF16 ? attn_fwd_t<bf16_t>(a, stream) : attn_fwd_t<float>(a, stream);
 }
 
 int mtn_attn_bwd_run(const AttnArgs& a, int dtype, hipStream_t stream) {
+    const bool x3 = dtype == MTN_F32X3 && attn_x3_fits(a.N);
+    dtype = mtn_storage_dtype(dtype);
     int rc = check_attn(a, dtype);
     if (rc) return rc;
+    if (x3) return attn_bwd_t<f32x3_t>(a, stream);
     return dtype == MTN_BF16 ? attn_bwd_t<bf16_t>(a, stream) : attn_bwd_t<float>(a, stream);
 }

@@ -313,14 +313,14 @@ int mtn_attention_fwd(const void* qkv, void* out, float* lse, float* attn, int d
                       float scale, void* stream) {
     AttnArgs a{};
     a.qkv = qkv; a.out = out; a.lse = lse; a.attn = attn; a.B = B; a.N = N; a.H = H; a.D = D; a.scale = scale;
-    return mtn_attn_fwd_run(a, mtn_storage_dtype(dtype), (hipStream_t)stream);
+    return mtn_attn_fwd_run(a, dtype, (hipStream_t)stream);
 }
 int mtn_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                       int dtype, int B, int N, int H, int D, float scale, void* stream) {
     AttnArgs a{};
     a.qkv = qkv; a.out = const_cast<void*>(out); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta;
     a.dqkv = dqkv; a.B = B; a.N = N; a.H = H; a.D = D; a.scale = scale;
-    return mtn_attn_bwd_run(a, mtn_storage_dtype(dtype), (hipStream_t)stream);
+    return mtn_attn_bwd_run(a, dtype, (hipStream_t)stream);
 }
 int mtn_cls_head_fwd(const void* tok, long long tok_stride, const float* ln_w, const float* ln_b, const float* W,
                      const float* bias, float* logits, float* xhat, float* mean_rstd, int dtype, int B, int C, float eps,
@@ -413,6 +413,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 15) { mtn_dgrad2_set(value); return MTN_OK; }
     if (key == 16) { mtn_igemm_set_image_tiles(value); return MTN_OK; }
     if (key == 18) { mtn_wgrad_set_row3(value); return MTN_OK; }
+    if (key == 19) { mtn_igemm_set_x3_waves(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

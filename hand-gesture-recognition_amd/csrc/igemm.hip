@@ -788,6 +788,7 @@ int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
 }
 
 static int g_igemm_dbg = 0;
+static int g_x3_waves = 8;       // debug key 19: 4 = the 128x128 tile of the split-bf16 mode runs 2x2 waves
 static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 = 64x128, 3 = 128x64 (N % 128 == 0 only)
 
 // 0: 128x128, 1: 64x128, 2: 256x64, 3: 128x64
@@ -820,6 +821,11 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     // 128x128 runs with 8 waves (4x2, 32x64 per wave) in the default pipelines: an LDS-DMA
     // instruction costs its wave ~100 cycles of issue, so 4 pieces per wave instead of 8 shorten the
     // load phase of every K step (+5..7 % on these layers; the smaller tiles measured -2..4 %)
+    if constexpr (std::is_same<T, f32x3_t>::value) {
+        // split-bf16 products convert every fragment in registers (24 VALU per fragment): 64x64 wave tiles
+        // (2x2 waves) need 8 fragments per 48 MFMAs where the 8-wave layout needs 6 per 24 (debug key 19)
+        if (cfg == 0 && g_igemm_stages == 5 && g_x3_waves == 4) return launch_igemm_dma2<T, 128, 128, 2, 2>(p, stream);
+    }
     if (cfg == 0 && g_igemm_stages == 5) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
     if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
@@ -847,6 +853,7 @@ int mtn_igemm_read_stamps(void* dst, size_t bytes) {
 #endif
 }
 void mtn_igemm_set_dbg(int v) { g_igemm_dbg = v; }
+void mtn_igemm_set_x3_waves(int v) { g_x3_waves = v == 4 ? 4 : 8; }
 
 int mtn_igemm_tiles_m(int M, int N, int K) {
     static const int bm[4] = {128, 64, 256, 128};

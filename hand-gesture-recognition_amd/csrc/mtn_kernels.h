@@ -166,6 +166,7 @@ void mtn_igemm_set_tile_n64(int rows);
 void mtn_wgrad_set_dma(int on);
 void mtn_igemm_set_tile(int t);
 void mtn_igemm_set_dbg(int v);
+void mtn_igemm_set_x3_waves(int v);
 void mtn_igemm_set_window_limit(int kb);
 void mtn_igemm_set_image_tiles(int on);
 int mtn_igemm_read_stamps(void* dst, size_t bytes);

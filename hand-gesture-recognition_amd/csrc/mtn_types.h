@@ -331,6 +331,14 @@ __device__ __forceinline__ float rcpf_(float x) {
     return __builtin_amdgcn_rcpf(x);
 #endif
 }
+// 2^x by v_exp_f32 (softmax: exp(s) = 2^(s log2 e), the factor folded into the score scale)
+__device__ __forceinline__ float exp2f_(float x) {
+#ifdef MTN_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_grad_(float x) {   // d/dx x*sigmoid(x)

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import DTYPES, be, rel_err, tol  # noqa: F401
+from backend import DTYPES, GEMM_DTYPES, be, rel_err, tol  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
@@ -107,13 +107,14 @@ def _attn_ref(qkv, B, N, H, D):
     return (attn @ v).permute(0, 2, 1, 3).reshape(B * N, H * D), attn
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 5, 2), (1, 37, 8), (8, 5, 2), (1, 145, 2), (1, 200, 1)])
-def test_attention_fwd_bwd(be, dtype, cfg):
+@pytest.mark.parametrize("dtype", GEMM_DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 5, 2), (1, 37, 8), (8, 5, 2), (1, 145, 2), (1, 200, 1), (1, 577, 1)])
+def test_attention_fwd_bwd(be, dtype, cfg, request):
     B, N, H = cfg
     D = 32
     if be.name == "emu" and N > 150:
         pytest.skip("long sequences on the GPU only")
+    x3 = request.node.get_closest_marker("x3") is not None        # split-bf16 products: ~1e-5 (N = 577: exact-f32 fallback)
     d = be.device
     qkv = _rand((B * N, 3 * H * D), dtype, 12)
     dout = _rand((B * N, H * D), dtype, 13)
@@ -126,13 +127,13 @@ def test_attention_fwd_bwd(be, dtype, cfg):
     attn = torch.full((B, H, N, N), float("nan"), device=d)
     ops.attention_fwd(qd, out, lse, attn, B, N, H, D, D ** -0.5)
     be.sync()
-    assert rel_err(out.float(), oref) < tol(dtype, 1e-5, 2e-2)
-    assert rel_err(attn, aref) < tol(dtype, 1e-5, 2e-2)
+    assert rel_err(out.float(), oref) < tol(dtype, 5e-5 if x3 else 1e-5, 2e-2)
+    assert rel_err(attn, aref) < tol(dtype, 5e-5 if x3 else 1e-5, 2e-2)
     delta = torch.empty((B * H, N), device=d)
     dqkv = torch.full((B * N, 3 * H * D), float("nan"), dtype=dtype, device=d)
     ops.attention_bwd(qd, out, dout.to(d), lse, delta, dqkv, B, N, H, D, D ** -0.5)
     be.sync()
-    assert rel_err(dqkv.float(), qr.grad) < tol(dtype, 2e-5, 3e-2)
+    assert rel_err(dqkv.float(), qr.grad) < tol(dtype, 1e-4 if x3 else 2e-5, 3e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
