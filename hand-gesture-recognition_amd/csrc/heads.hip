@@ -724,13 +724,17 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
     constexpr int PR = DIM + PAD;                    // sR rows (channels contiguous)
     constexpr int PD = OWK + PAD;                    // sD rows (output columns contiguous)
     constexpr int PWT = 32 + PAD;                    // sWt rows (joints contiguous)
-    constexpr int PG = DIM + 4;                      // sG rows, f32
+    // G is staged in f32, except for the 96-column maps of 384x384 images in bf16 mode: there the f32 tile
+    // (100 KB) would push the workgroup past 160 KB of LDS (and the kernel back to the 12x slower chunk kernel),
+    // so it is staged in T -- one rounding to bf16 of a term of a token gradient that is stored in bf16 anyway
+    typedef typename std::conditional<(WT >= 24 && sizeof(T) == 2), T, float>::type GT;
+    constexpr int PG = DIM + 16 / (int)sizeof(GT);   // sG rows
     constexpr int NT = 512;
     constexpr int ND = (32 * OW + NT - 1) / NT;      // heat-map gradient elements per thread per row (joints padded to 32)
     constexpr int NPF = OWM / 16;
     static_assert(OH2 <= 64, "ReLU mask bits");
     MTN_DYN_SMEM(smem);
-    float* sG = reinterpret_cast<float*>(smem);      // [OWM][PG] f32
+    GT* sG = reinterpret_cast<GT*>(smem);            // [OWM][PG]
     T* sR = reinterpret_cast<T*>(sG + OWM * PG);     // [OWK][PR]  relu(u) (rows >= OW: zero)
     T* sD = sR + OWK * PR;                           // [32][PD]   D (columns >= OW and rows >= J: zero)
     T* sWt = sD + 32 * PD;                           // [DIM][PWT] W^T (joints >= J: zero)
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
         MTN_UNROLL for (int o = 0; o < OH2; ++o) {
             const int ox = HALF * OH2 + o;
             const Lerp lx = lerp_coord(ox, WT, OW);
-            const float g = ((mask >> o) & 1ull) ? sG[ox * PG + ch] : 0.f;
+            const float g = ((mask >> o) & 1ull) ? to_f<GT>(sG[ox * PG + ch]) : 0.f;
             tx[lx.i0] += (1.f - lx.w1) * g;
             if (lx.i1 != lx.i0) tx[lx.i1] += lx.w1 * g;
         }
@@ -846,7 +850,7 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
             }
             MTN_UNROLL for (int pf = 0; pf < NPF; ++pf)
                 MTN_UNROLL for (int q = 0; q < 2; ++q)
-                    store4<float>(sG + (pf * 16 + (lane & 15)) * PG + (wid * 2 + q) * 16 + 4 * (lane >> 4), g[pf][q]);
+                    store4<GT>(sG + (pf * 16 + (lane & 15)) * PG + (wid * 2 + q) * 16 + 4 * (lane >> 4), g[pf][q]);
         }
         __syncthreads();                             // sG complete; everyone is done with sR / sD
         MTN_UNROLL for (int sx = 0; sx < WT; ++sx) tx[sx] = 0.f;
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
         }
     // dbias[j] = sum of this image's gradient row j: element i always belongs to joint i / OW
     __syncthreads();
-    float* red = sG;                                 // [32 * OW]
+    float* red = reinterpret_cast<float*>(sG);       // [32 * OW] f32 (12 KB at most: inside the G tile either way)
     MTN_UNROLL for (int k = 0; k < ND; ++k) { const int i = tid + NT * k; if (i < 32 * OW) red[i] = db[k]; }
     __syncthreads();
     if (tid < J) {
@@ -879,7 +883,8 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
 template <class T>
 static size_t pose_bwd_row_lds(int w) {
     const int OW = 4 * w, OWM = (OW + 15) & ~15, OWK = (OW + 31) & ~31, pad = 16 / (int)sizeof(T);
-    return (size_t)OWM * (DIM + 4) * 4 + ((size_t)OWK * (DIM + pad) + 32 * (size_t)(OWK + pad) + (size_t)DIM * (32 + pad)) * sizeof(T);
+    const size_t gsz = (w >= 24 && sizeof(T) == 2) ? sizeof(T) : 4;       // element size of the staged G tile (GT in the kernel)
+    return (size_t)OWM * (DIM + 16 / gsz) * gsz + ((size_t)OWK * (DIM + pad) + 32 * (size_t)(OWK + pad) + (size_t)DIM * (32 + pad)) * sizeof(T);
 }
 template <class T, int WT>
 static void pose_bwd_row_launch(int B, size_t lds, hipStream_t stream, const void* tok, const float* W, const float* dhm, void* dtok,
