@@ -354,7 +354,7 @@ int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 }
 int mtn_pack_weights(const float* src, const float* scale, void* dst, const int* desc, int ntensors, int max_elems, int dtype,
                      void* stream) {
-    return mtn_pack_run(src, scale, dst, desc, ntensors, max_elems, mtn_storage_dtype(dtype), (hipStream_t)stream);
+    return mtn_pack_run(src, scale, dst, desc, ntensors, max_elems, dtype, (hipStream_t)stream);
 }
 
 int mtn_heatmap_argmax(const float* hm, float* preds, float* maxvals, int maps, int H, int W, void* stream) {

@@ -127,7 +127,7 @@ void dgrad2_kernel(IgemmArgs p) {
         auto load = [&](int s, int buf) {
             const int cs = s / KS, ks = s % KS;
             MTN_UNROLL for (int j = 0; j < FN; ++j)
-                fb[buf][j] = RowFrag<T>::load(wb + (cs * BN + j * 16) * BK, ks, fg, swb);
+                fb[buf][j] = RowFragW<T>::load(wb + (cs * BN + j * 16) * BK, ks, fg, swb);
             MTN_UNROLL for (int i = 0; i < FM; ++i)
                 fa[buf][i] = RowFrag<T>::load(sWin + aoff[i] + cs * acs[i], ks, fg, asw[i]);
         };

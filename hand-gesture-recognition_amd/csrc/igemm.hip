@@ -305,9 +305,32 @@ void igemm_kernel(IgemmArgs p) {
             buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
                        b + (wid * RB + i) * 1024);
     };
+    constexpr bool X3 = std::is_same<T, f32x3_t>::value;
     auto store_tiles = [&](int stage) {
         T* a = sA + stage * BM * PITCH;
         T* b = sB + stage * BN * PITCH;
+        if constexpr (X3) {
+            // split-on-store: the 144-byte row holds [32 hi bf16][32 lo bf16][pad]; this thread's 4 values land at
+            // byte 8 * chunk of either half (mtn_types.h: Split4)
+            auto put = [&](T* rowp, const chunk16& c) {
+                const Split4 s = split_pack4(c);
+                // chunk c = k 4c..4c+3 -> slot (c & 3), first / second half of the slot (x3_block_pos)
+                char* q = reinterpret_cast<char*>(rowp) + (chunk & 3) * 16 + (chunk >> 2) * 8;
+#ifdef MTN_EMU
+                std::memcpy(q, s.hi, 8); std::memcpy(q + 64, s.lo, 8);
+#else
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 h, l;
+                h[0] = s.hi[0]; h[1] = s.hi[1]; l[0] = s.lo[0]; l[1] = s.lo[1];
+                *reinterpret_cast<u32x2*>(q) = h;
+                *reinterpret_cast<u32x2*>(q + 64) = l;
+#endif
+            };
+            MTN_UNROLL for (int i = 0; i < RA; ++i) put(a + (row0 + i * RSTEP) * PITCH, ra[i]);
+            MTN_UNROLL for (int i = 0; i < RB; ++i)          // the weights arrive pre-split: the same bytes, copied
+                *reinterpret_cast<chunk16*>(b + (row0 + i * RSTEP) * PITCH + chunk * VEC) = rb[i];
+            return;
+        }
         MTN_UNROLL for (int i = 0; i < RA; ++i)
             *reinterpret_cast<chunk16*>(a + (row0 + i * RSTEP) * PITCH + chunk * VEC) = ra[i];
         MTN_UNROLL for (int i = 0; i < RB; ++i)
@@ -401,7 +424,7 @@ void igemm_kernel(IgemmArgs p) {
             asw[i] = j & 7;
         }
         mma_step([&](int ks, int i) { return RowFrag<T>::load(sB + aoff[i], ks, fg, asw[i]); },
-                 [&](int ks, int j) { return RowFrag<T>::load(b + j * 16 * BK, ks, fg, swb); });
+                 [&](int ks, int j) { return RowFragW<T>::load(b + j * 16 * BK, ks, fg, swb); });
     };
 
     auto compute = [&](int stage) {
@@ -411,7 +434,24 @@ void igemm_kernel(IgemmArgs p) {
             const T* b = sB + stage * BN * BK + (wn * WN + frow) * BK;
             const int sw = frow & 7;                       // (row & 7): tile bases are multiples of 16
             mma_step([&](int ks, int i) { return RowFrag<T>::load(a + i * 16 * BK, ks, fg, sw); },
-                     [&](int ks, int j) { return RowFrag<T>::load(b + j * 16 * BK, ks, fg, sw); });
+                     [&](int ks, int j) { return RowFragW<T>::load(b + j * 16 * BK, ks, fg, sw); });
+            return;
+        }
+        if constexpr (X3) {
+            // tiles written split-on-store: fragments are plain bf16x8 reads of the hi and the lo half of a row
+            const char* a = reinterpret_cast<const char*>(sA + stage * BM * PITCH + (wm * WM + frow) * PITCH) + 16 * fg;
+            const char* b = reinterpret_cast<const char*>(sB + stage * BN * PITCH + (wn * WN + frow) * PITCH) + 16 * fg;
+            Frag3 fa[FM], fb[FN];
+            MTN_UNROLL for (int i = 0; i < FM; ++i) {
+                fa[i].hi = load_bf16x8(a + i * 16 * PITCH_BYTES);
+                fa[i].lo = load_bf16x8(a + i * 16 * PITCH_BYTES + 64);
+            }
+            MTN_UNROLL for (int j = 0; j < FN; ++j) {
+                fb[j].hi = load_bf16x8(b + j * 16 * PITCH_BYTES);
+                fb[j].lo = load_bf16x8(b + j * 16 * PITCH_BYTES + 64);
+            }
+            MTN_UNROLL for (int i = 0; i < FM; ++i)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
             return;
         }
         const T* a = sA + stage * BM * PITCH + (wm * WM + frow) * PITCH + fk;
@@ -767,12 +807,12 @@ static bool igemm_pointwise(const IgemmArgs& p) {
 }
 
 // the default LDS-DMA double-buffer pipeline, specialised on the tap set
-template <class T, int BM, int BN, int WGM, int WGN>
+template <class T, int BM, int BN, int WGM, int WGN, int STG = 3>
 int launch_igemm_dma2(const IgemmArgs& p, hipStream_t stream) {
-    if (igemm_pointwise(p) && p.act == MTN_ACT_GELU_GRAD_) return launch_igemm<T, BM, BN, WGM, WGN, 3, 4>(p, stream);
-    if (igemm_pointwise(p)) return launch_igemm<T, BM, BN, WGM, WGN, 3, 1>(p, stream);
-    if (p.KH == 3 && p.KW == 3) return p.pm ? launch_igemm<T, BM, BN, WGM, WGN, 3, 3>(p, stream) : launch_igemm<T, BM, BN, WGM, WGN, 3, 2>(p, stream);
-    return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
+    if (igemm_pointwise(p) && p.act == MTN_ACT_GELU_GRAD_) return launch_igemm<T, BM, BN, WGM, WGN, STG, 4>(p, stream);
+    if (igemm_pointwise(p)) return launch_igemm<T, BM, BN, WGM, WGN, STG, 1>(p, stream);
+    if (p.KH == 3 && p.KW == 3) return p.pm ? launch_igemm<T, BM, BN, WGM, WGN, STG, 3>(p, stream) : launch_igemm<T, BM, BN, WGM, WGN, STG, 2>(p, stream);
+    return launch_igemm<T, BM, BN, WGM, WGN, STG>(p, stream);
 }
 
 template <class T, int BM, int BN, int WGM, int WGN>
@@ -825,6 +865,12 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
         // split-bf16 products convert every fragment in registers (24 VALU per fragment): 64x64 wave tiles
         // (2x2 waves) need 8 fragments per 48 MFMAs where the 8-wave layout needs 6 per 24 (debug key 19)
         if (cfg == 0 && g_igemm_stages == 5 && g_x3_waves == 4) return launch_igemm_dma2<T, 128, 128, 2, 2>(p, stream);
+        // debug key 19 = 2: register-staged double buffer with split-on-store tiles (each element converted once)
+        if (g_igemm_stages == 5 && g_x3_waves == 2) {
+            if (cfg == 0) return launch_igemm_dma2<T, 128, 128, 4, 2, 2>(p, stream);
+            if (cfg == 1) return launch_igemm_dma2<T, 64, 128, 1, 4, 2>(p, stream);
+            if (cfg == 3) return launch_igemm_dma2<T, 128, 64, 4, 1, 2>(p, stream);
+        }
     }
     if (cfg == 0 && g_igemm_stages == 5) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
     if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
@@ -853,7 +899,7 @@ int mtn_igemm_read_stamps(void* dst, size_t bytes) {
 #endif
 }
 void mtn_igemm_set_dbg(int v) { g_igemm_dbg = v; }
-void mtn_igemm_set_x3_waves(int v) { g_x3_waves = v == 4 ? 4 : 8; }
+void mtn_igemm_set_x3_waves(int v) { g_x3_waves = (v == 4 || v == 2) ? v : 8; }
 
 int mtn_igemm_tiles_m(int M, int N, int K) {
     static const int bm[4] = {128, 64, 256, 128};

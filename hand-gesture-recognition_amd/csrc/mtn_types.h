@@ -215,6 +215,32 @@ template <> struct Mma<f32x3_t> {
     }
 };
 
+// Split-on-store form (register-staged pipelines): four fp32 values -> 4 bf16 hi (8 bytes) + 4 bf16 lo (8 bytes).  A tile
+// written this way holds a row as [32 hi][32 lo] bf16 and its fragments are plain 16-byte bf16x8 reads: every element is
+// converted ONCE on its way into LDS instead of once per wave that reads it (24 VALU per fragment and wave otherwise).
+struct Split4 { unsigned hi[2], lo[2]; };
+__device__ __forceinline__ Split4 split_pack4(const chunk16& c) {
+    float x[4];
+    unpack<float>(c, x);
+    unsigned short h[4], l[4];
+    MTN_UNROLL for (int j = 0; j < 4; ++j) {
+        const bf16_t hb = f2bf(x[j]);
+        h[j] = hb.v;
+        l[j] = f2bf(x[j] - bf2f(hb)).v;
+    }
+    Split4 s;
+    s.hi[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); s.hi[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    s.lo[0] = (unsigned)l[0] | ((unsigned)l[1] << 16); s.lo[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+    return s;
+}
+__device__ __forceinline__ bf16x8_t load_bf16x8(const void* p) {
+#ifdef MTN_EMU
+    bf16x8_t f; std::memcpy(&f, p, 16); return f;
+#else
+    return *reinterpret_cast<const bf16x8_t*>(p);
+#endif
+}
+
 // Operand fragment of K-sub-step ks from a ROW of an XOR-swizzled row-major LDS tile (128-byte rows of
 // 16-byte slots, slot s of row r stored at slot s ^ (r & 7); `sw` = r & 7, g = lane >> 4).
 template <class T> struct RowFrag {
@@ -222,6 +248,26 @@ template <class T> struct RowFrag {
     static __device__ __forceinline__ typename Mma<T>::Frag load(const T* row, int ks, int g, int sw) {
         const int e = ks * KI + g * (KI / 4);
         return Mma<T>::load(row + (((e / VEC) ^ sw) * VEC) + (e % VEC));
+    }
+};
+// WEIGHT operand of the split-bf16 mode: the pack kernel (optim.hip) already stores every 32-k block of a weight row
+// as [32 hi bf16][32 lo bf16] = the same 128 bytes the fp32 block would take, in the k order the activation fragment
+// above uses (16-byte slot g = k {4g..4g+3, 16+4g..16+4g+3}, hi in slots 0..3, lo in slots 4..7).  Its fragments are two
+// plain 16-byte reads and NO conversion: the weights are converted once per step by the pack launch instead of once per
+// wave, K step and tile that reads them (4 of the 6 fragments a 32x64 wave tile reads per K step are weights).
+__device__ __forceinline__ int x3_block_pos(int j) {              // position (bf16 index, 0..31) of k-in-block j inside a half
+    return ((j & 15) >> 2) * 8 + (j >> 4) * 4 + (j & 3);
+}
+template <class T> struct RowFragW {
+    static __device__ __forceinline__ typename Mma<T>::Frag load(const T* row, int ks, int g, int sw) { return RowFrag<T>::load(row, ks, g, sw); }
+};
+template <> struct RowFragW<f32x3_t> {
+    static __device__ __forceinline__ Frag3 load(const f32x3_t* row, int ks, int g, int sw) {
+        (void)ks;
+        Frag3 f;
+        f.hi = load_bf16x8(row + ((g ^ sw) * 4));
+        f.lo = load_bf16x8(row + (((g + 4) ^ sw) * 4));
+        return f;
     }
 };
 template <> struct RowFrag<f32x3_t> {

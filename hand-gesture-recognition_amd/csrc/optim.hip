@@ -9,6 +9,7 @@
 //
 // state f32[16]: 0 lr, 1 beta1, 2 beta2, 3 eps, 4 weight_decay, 5 step, 6 bias_corr1,
 //                7 bias_corr2, 8 grad_scale
+#include <type_traits>
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
@@ -50,7 +51,24 @@ template <class T>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, const float* __restrict__ scale,
                                                    T* __restrict__ dst, const int* __restrict__ desc) {
     const int* d = desc + blockIdx.y * 7;
-    const int so = d[0], dof = d[1], O = d[2], I = d[3], taps = d[4], mode = d[5];
+    const int so = d[0], dof = d[1], O = d[2], I = d[3], taps = d[4], mode = d[5] & 1;
+    // split-bf16 mode (T = f32x3_t): a packed row of K values is stored as K / 32 blocks of [32 hi bf16][32 lo bf16] in the
+    // k order of the kernels' fragments (mtn_types.h RowFragW) unless the tensor asks for plain fp32 (d[5] & 2: the stem,
+    // whose kernels multiply in exact f32).  Same bytes, same offsets: element (row, k) of the fp32 layout becomes two
+    // bf16 at (row, block k / 32, x3_block_pos(k % 32)) of the hi and the lo half.
+    constexpr bool X3 = std::is_same<T, f32x3_t>::value;
+    const bool presplit = X3 && !(d[5] & 2);
+    auto put = [&](long row_len, long row, int k, float v) {
+        if (presplit) {
+            bf16_t* base = reinterpret_cast<bf16_t*>(dst + dof + row * row_len + (k & ~31));
+            const bf16_t h = f2bf(v);
+            const int pos = x3_block_pos(k & 31);
+            base[pos] = h;
+            base[32 + pos] = f2bf(v - bf2f(h));
+        } else {
+            dst[dof + row * row_len + k] = from_f<T>(v);
+        }
+    };
     // d[6] >= 0: fold a per-output-channel factor scale[d[6] + o] into the weights (inference: the BatchNorm's
     // gamma / sqrt(running_var + eps), export.py:41-45 runs the model in eval()); forward layout only
     const float* sc = (d[6] >= 0 && scale != nullptr && mode == 0) ? scale + d[6] : nullptr;
@@ -72,7 +90,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
             __syncthreads();
             MTN_UNROLL for (int k = 0; k < 16; ++k) {
                 const int c = c0 + ty + 4 * k, r = r0 + tx;
-                if (c < Cn && r < R) dst[dof + c * R + r] = from_f<T>(tile[tx][ty + 4 * k]);
+                // destination row = input channel i = c / taps, its K index = (c % taps) * R + r
+                if (c < Cn && r < R) put((long)taps * R, c / taps, (c % taps) * R + r, tile[tx][ty + 4 * k]);
             }
             __syncthreads();
         }
@@ -90,7 +109,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
         else { outer = q / taps; tap = q - outer * taps; }
         const int o = mode == 0 ? outer : f, i = mode == 0 ? f : outer;
         const float wv = src[so + (o * I + i) * taps + tap];
-        dst[dof + idx] = from_f<T>(sc ? wv * sc[o] : wv);
+        // (idx = outer * (taps * inner) + tap * inner + f: row = outer, K index = tap * inner + f)
+        put((long)taps * inner, outer, tap * inner + f, sc ? wv * sc[o] : wv);
     }
 }
 
@@ -112,6 +132,7 @@ int mtn_pack_run(const float* src, const float* scale, void* dst, const int* des
     int bx = (max_elems + 255) / 256;
     if (bx > 256) bx = 256;
     if (dtype == MTN_BF16) MTN_LAUNCH(pack_kernel<bf16_t>, dim3(bx, ntensors), dim3(256), 0, stream, src, scale, (bf16_t*)dst, desc);
+    else if (dtype == MTN_F32X3) MTN_LAUNCH(pack_kernel<f32x3_t>, dim3(bx, ntensors), dim3(256), 0, stream, src, scale, (f32x3_t*)dst, desc);
     else MTN_LAUNCH(pack_kernel<float>, dim3(bx, ntensors), dim3(256), 0, stream, src, scale, (float*)dst, desc);
     return mtn_check_launch("pack");
 }

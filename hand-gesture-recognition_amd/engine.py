@@ -132,7 +132,8 @@ class Engine:
             wgt = u.mod.weight if isinstance(u.mod, torch.nn.Conv2d) else u.mod.conv.weight
             u.weight = wgt
             u.pk_row = len(desc)                     # row of the forward-layout entry in the pack table
-            u.pk_f = add_pack(wgt, u.cout, u.cin, u.k * u.k, 0)
+            # (mode + 2: plain fp32 also in the split-bf16 mode -- the stem kernels multiply in exact f32)
+            u.pk_f = add_pack(wgt, u.cout, u.cin, u.k * u.k, 2 if u is self.u_conv1 else 0)
             u.pk_d = add_pack(wgt, u.cout, u.cin, u.k * u.k, 1) if u is not self.u_conv1 else None
             packs.append(u)
         self.layers = []

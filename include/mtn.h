@@ -248,7 +248,11 @@ int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
  * scale_off >= 0 (mode 0 only, scale != NULL): the weights of output channel o are multiplied by
  * scale[scale_off + o] -- inference with BatchNorm folded into the convolution (the reference runs its
  * model in eval() for export / evaluation, export.py:41-45): scale = gamma / sqrt(running_var + eps) from
- * mtn_bn_eval_scale_shift, the matching shift goes to mtn_conv_bias_act_fwd as its bias.  -1: no factor. */
+ * mtn_bn_eval_scale_shift, the matching shift goes to mtn_conv_bias_act_fwd as its bias.  -1: no factor.
+ * dtype MTN_DTYPE_F32X3: the GEMM-shaped entry points expect their WEIGHT operand pre-split -- every 32-k block of a
+ * packed row as [32 bf16 hi][32 bf16 lo] (the 128 bytes of the fp32 block, k order of the kernels' fragments) -- which is
+ * what this function writes under that dtype; mode + 2 keeps a tensor in plain fp32 (the stem: mtn_conv1_* multiply in
+ * exact f32).  Packed row lengths (I*taps for mode 0, O*taps for mode 1) must then be multiples of 32. */
 int mtn_pack_weights(const float* src, const float* scale, void* dst, const int* desc, int ntensors,
                      int max_elems, int dtype, void* stream);
 
