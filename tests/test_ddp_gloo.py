@@ -140,10 +140,13 @@ def _gpu_two_rank_worker(rank, world, port, outdir):
         step = TrainStep(model, 8, lr=1e-3, overlap_comm=mode)
         assert step.world == 2 and step.overlap == mode
         grads = []
+        step.comm_events = []                          # bench.py's instrumentation: event pairs around the wait for the all-reduce
         for _ in range(3):
             losses = step(*batch)
             grads.append(model.flat_grads.clone())
         torch.cuda.synchronize()
+        assert len(step.comm_events) == 3 and 0.0 <= step.comm_exposed_ms() < 1e3
+        step.comm_events = None
         res[mode] = (model.flat_params.clone().cpu(), [g.cpu() for g in grads], losses.clone().cpu())
     torch.save(res, os.path.join(outdir, f"gpu{rank}.pt"))
     dist.barrier()
