@@ -17,6 +17,7 @@
 // head_dim = 32 is exactly one bf16 MFMA K step.  Backward recomputes P from the saved
 // log-sum-exp (flash style); only the last layer's probabilities are written (they are the
 // module's attnmap output, transformer.py:96,152).
+#include <type_traits>
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
@@ -177,7 +178,11 @@ __device__ __forceinline__ int attn_bh(int H) {
 }
 
 // ---- forward ------------------------------------------------------------------------------------
-template <class T, int MAXT>
+// FULL: the padded sequence is exactly MAXT key tiles (145 tokens -> 10, 577 -> 38: the model's two sequence lengths).
+// With a runtime tile count every `kt < nkt` guard of the unrolled loops is a real branch and hipcc serialises each tile
+// as LDS read -> s_waitcnt 0 -> MFMA -> s_nop -> dependent selects (seen in the ISA); with the count a compile-time
+// constant the MFMAs of a query tile issue back to back and only the last two tiles carry a padded-key mask.
+template <class T, int MAXT, bool FULL>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
                                                        float* __restrict__ attn, int N, int H, float scale) {
     constexpr int PITCH = Lay<T>::PITCH;
@@ -215,11 +220,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         f32x4_t s[MAXT];
         float mx = -3.0e38f;
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
-            if (kt < nkt) {
+            if (FULL || kt < nkt) {
                 RowOp<T> kf;
                 kf.load(sK + (kt * 16 + li) * PITCH, true, g);
                 s[kt] = mma32(kf, qf, zero4());
-                if (kt * 16 + 16 > N) {                    // (wave-uniform) tile with padded keys
+            }
+        }
+        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
+            if (FULL || kt < nkt) {
+                if (FULL ? (kt >= MAXT - 2) : (kt * 16 + 16 > N)) {      // only these tiles can hold padded keys
                     MTN_UNROLL for (int r = 0; r < 4; ++r)
                         if (kt * 16 + 4 * g + r >= N) s[kt][r] = -3.0e38f;
                 }
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         const float c2 = scale * 1.4426950408889634f, mc = mx * c2;
         float sum = 0.f;
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
-            if (kt < nkt) {
+            if (FULL || kt < nkt) {
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
                     const float e = exp2f_(fmaf(s[kt][r], c2, -mc));
                     s[kt][r] = e;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         if (qok && g == 0) lse[(long)bh * N + q] = mx * scale + __logf(sum);
         if (attn && qok) {
             MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
-                if (kt < nkt) {
+                if (FULL || kt < nkt) {
                     float* ap = attn + ((long)bh * N + q) * N + kt * 16 + 4 * g;
                     MTN_UNROLL for (int r = 0; r < 4; ++r)
                         if (kt * 16 + 4 * g + r < N) ap[r] = s[kt][r] * inv;
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         }
         f32x4_t o0 = zero4(), o1 = zero4();
         MTN_UNROLL for (int pr = 0; pr < MAXT / 2; ++pr) {
-            if (2 * pr < nkt) {
+            if (FULL || 2 * pr < nkt) {
                 o0 = acc_mma(sV + pr * 32 * PITCH, PITCH, s[2 * pr], s[2 * pr + 1], o0, lane);
                 o1 = acc_mma(sV + pr * 32 * PITCH + 16, PITCH, s[2 * pr], s[2 * pr + 1], o1, lane);
             }
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ---- backward 1: dQ (sums over keys) and delta = rowsum(dO * O) ----------------------------------
-template <class T, int MAXT>
+template <class T, int MAXT, bool FULL>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, T* __restrict__ dqkv, int N, int H,
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
         if (qok && g == 0) delta[(long)bh * N + q] = dl;
         f32x4_t ds[MAXT];
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
-            if (kt < nkt) {
+            if (FULL || kt < nkt) {
                 RowOp<T> kf, vf;
                 kf.load(sK + (kt * 16 + li) * PITCH, true, g);
                 vf.load(sV + (kt * 16 + li) * PITCH, true, g);
@@ -320,15 +329,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
                     const float p = exp2f_(fmaf(s[r], c2, -lq2));
                     ds[kt][r] = p * (dp[r] - dl) * scale;
                 }
-                if (kt * 16 + 16 > N) {                    // (wave-uniform) tile with padded keys: exp(0 - lse) may overflow
+                if (FULL ? (kt >= MAXT - 2) : (kt * 16 + 16 > N)) {   // tiles that can hold padded keys: exp(0 - lse) may overflow
                     MTN_UNROLL for (int r = 0; r < 4; ++r)
                         if (kt * 16 + 4 * g + r >= N) ds[kt][r] = 0.f;
                 }
             }
+            // groups of four tiles: enough independent MFMAs in flight, without hoisting all 2 x MAXT score tiles into
+            // registers at once (the fully unrolled form spilled 100-700 registers)
+            if (FULL && (kt & 3) == 3) MTN_SCHED_FENCE();
         }
         f32x4_t d0 = zero4(), d1 = zero4();
         MTN_UNROLL for (int pr = 0; pr < MAXT / 2; ++pr) {
-            if (2 * pr < nkt) {
+            if (FULL || 2 * pr < nkt) {
                 d0 = acc_mma(sK + pr * 32 * PITCH, PITCH, ds[2 * pr], ds[2 * pr + 1], d0, lane);
                 d1 = acc_mma(sK + pr * 32 * PITCH + 16, PITCH, ds[2 * pr], ds[2 * pr + 1], d1, lane);
             }
@@ -428,13 +440,17 @@ int attn_fwd_t(const AttnArgs& a, hipStream_t stream) {
     const int NP = (a.N + 31) & ~31;
     const size_t lds = 2 * (size_t)NP * Lay<T>::PITCH * sizeof(T);
     const dim3 grid(a.B * a.H), block(NP / 16 <= 10 ? 256 : 512);   // long sequences: 1 WG/CU -> 8 waves
-    if (NP / 16 <= 10) {
-        set_max_lds(attn_fwd_kernel<T, 10>, lds);
-        MTN_LAUNCH((attn_fwd_kernel<T, 10>), grid, block, lds, stream, (const T*)a.qkv, (T*)a.out, a.lse, a.attn, a.N, a.H, a.scale);
-    } else {
-        set_max_lds(attn_fwd_kernel<T, 38>, lds);
-        MTN_LAUNCH((attn_fwd_kernel<T, 38>), grid, block, lds, stream, (const T*)a.qkv, (T*)a.out, a.lse, a.attn, a.N, a.H, a.scale);
-    }
+#define MTN_ATTN_FWD(MT, FL)                                                                                                     \
+    do {                                                                                                                         \
+        set_max_lds(attn_fwd_kernel<T, MT, FL>, lds);                                                                            \
+        MTN_LAUNCH((attn_fwd_kernel<T, MT, FL>), grid, block, lds, stream, (const T*)a.qkv, (T*)a.out, a.lse, a.attn, a.N, a.H, \
+                   a.scale);                                                                                                     \
+    } while (0)
+    if (NP / 16 == 10) MTN_ATTN_FWD(10, true);
+    else if (NP / 16 < 10) MTN_ATTN_FWD(10, false);
+    else if (NP / 16 == 38 && !std::is_same<T, f32x3_t>::value) MTN_ATTN_FWD(38, true);    // (split-bf16 at 38 tiles spills either way)
+    else MTN_ATTN_FWD(38, false);
+#undef MTN_ATTN_FWD
     return mtn_check_launch("attn_fwd");
 }
 
@@ -443,15 +459,16 @@ int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
     const int NP = (a.N + 31) & ~31;
     const size_t lds = 2 * (size_t)NP * Lay<T>::PITCH * sizeof(T);
     const dim3 grid(a.B * a.H), block(NP / 16 <= 10 ? 256 : 512);
-    if (NP / 16 <= 10) {
-        set_max_lds(attn_bwd_dq_kernel<T, 10>, lds);
-        MTN_LAUNCH((attn_bwd_dq_kernel<T, 10>), grid, block, lds, stream, (const T*)a.qkv, (const T*)a.out, (const T*)a.dout,
-                   a.lse, a.delta, (T*)a.dqkv, a.N, a.H, a.scale);
-    } else {
-        set_max_lds(attn_bwd_dq_kernel<T, 38>, lds);
-        MTN_LAUNCH((attn_bwd_dq_kernel<T, 38>), grid, block, lds, stream, (const T*)a.qkv, (const T*)a.out, (const T*)a.dout,
-                   a.lse, a.delta, (T*)a.dqkv, a.N, a.H, a.scale);
-    }
+#define MTN_ATTN_DQ(MT, FL)                                                                                                      \
+    do {                                                                                                                         \
+        set_max_lds(attn_bwd_dq_kernel<T, MT, FL>, lds);                                                                         \
+        MTN_LAUNCH((attn_bwd_dq_kernel<T, MT, FL>), grid, block, lds, stream, (const T*)a.qkv, (const T*)a.out,                  \
+                   (const T*)a.dout, a.lse, a.delta, (T*)a.dqkv, a.N, a.H, a.scale);                                             \
+    } while (0)
+    if (NP / 16 == 10) MTN_ATTN_DQ(10, true);
+    else if (NP / 16 < 10) MTN_ATTN_DQ(10, false);
+    else MTN_ATTN_DQ(38, false);      // (38 tiles fully unrolled: ds[38] + the tile group in flight spill; the guarded form does not)
+#undef MTN_ATTN_DQ
     int rc = mtn_check_launch("attn_bwd_dq");
     if (rc) return rc;
     const size_t lds2 = lds + (sizeof(T) == 2 ? 2 * (size_t)NP * sizeof(float) : 0);
