@@ -9,9 +9,7 @@ one bucket each) and connects the plan to autograd.
 Deviations from the reference module, all deliberate:
   * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174)
     and, like the other outputs' backing storage, is overwritten by the next forward;
-  * parameter gradients are written (not accumulated) into ``p.grad`` by each backward -- the
-    reference's loop zeroes them every step (Lightning), so training is unaffected;
-  * the input needs no gradient (none is produced);
+  * the input gets no gradient (``x.grad`` stays None: nothing in the reference's training or export paths asks for it);
   * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode),
     fp32 storage / exact-f32 MFMA (validation mode), or "bf16x3": fp32 storage with split-bf16 matrix
     products (three MFMAs per product) -- both fp32-storage modes are held to 1e-3 of the reference.
@@ -111,6 +109,7 @@ class MultiTaskNet(nn.Module):
                 p.grad = None
                 off += k
         self.flat_params, self.flat_grads, self.n_params = flat, grads, n
+        self._grad_acc = None                     # what p.grad views (autograd semantics: backward ADDS into it), lazily
         # every re-flatten orphans the buffers that existing plans (Engine) and optimizers (TrainStep)
         # captured: they compare this counter with the one they were built at and refuse to run stale
         self._generation = getattr(self, "_generation", 0) + 1
@@ -134,7 +133,7 @@ class MultiTaskNet(nn.Module):
         parameters alias ITS flat_params (fused AdamW / all-reduce operate on the flat buffer)."""
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
-        skip = ("flat_params", "flat_grads", "_anchor", "_engines")
+        skip = ("flat_params", "flat_grads", "_anchor", "_engines", "_grad_acc")
         for k, v in self.__dict__.items():
             if k not in skip:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -154,13 +153,38 @@ class MultiTaskNet(nn.Module):
         return self
 
     def publish_grads(self):
-        """Expose the flat gradient buffer through ``p.grad`` (views, no copies)."""
+        """Give ``p.grad`` autograd's semantics after a ``loss.backward()`` through this module: the gradient of THIS
+        backward (the plan wrote it into ``flat_grads``) is ADDED to ``p.grad`` where one exists and becomes ``p.grad``
+        where it is None -- so ``accumulate_grad_batches``, two losses backpropagated in turn, and both forms of
+        ``zero_grad`` behave as with the reference module (model/multitasknet.py is a plain autograd module).
+        ``p.grad`` tensors are views of one flat accumulation buffer: the whole update is one ``add_`` / ``copy_`` in the
+        common cases.  (The fused ``TrainStep`` does not come through here: it consumes ``flat_grads`` directly.)"""
         if not self._views_ok():
             raise RuntimeError("MultiTaskNet parameters no longer alias flat_params (their storage was replaced after "
                                "the plan was built); call model._flatten() and rebuild the TrainStep")
-        for p in self.parameters():
-            if p.grad is not p._mtn_grad:
-                p.grad = p._mtn_grad
+        params = list(self.parameters())
+        if self._grad_acc is None or self._grad_acc.device != self.flat_grads.device:
+            self._grad_acc = torch.zeros_like(self.flat_grads)
+            off = 0
+            for p in params:
+                p._mtn_acc = self._grad_acc[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        # fresh: this parameter's p.grad is not (yet) our accumulation view -- None, or a tensor somebody else put there
+        fresh = [p.grad is None or p.grad.data_ptr() != p._mtn_acc.data_ptr() for p in params]
+        with torch.no_grad():
+            if not any(fresh):                               # accumulate (zero_grad(set_to_none=False) zeroed the views in place)
+                self._grad_acc.add_(self.flat_grads)
+                return
+            foreign = [p.grad if f else None for p, f in zip(params, fresh)]
+            if all(fresh):                                   # first backward / after zero_grad(set_to_none=True)
+                self._grad_acc.copy_(self.flat_grads)
+            else:                                            # mixed: per parameter
+                for p, f in zip(params, fresh):
+                    (p._mtn_acc.copy_ if f else p._mtn_acc.add_)(p._mtn_grad)
+            for p, g in zip(params, foreign):
+                if g is not None:
+                    p._mtn_acc.add_(g)                       # a gradient that was already there still counts
+                p.grad = p._mtn_acc
 
     def set_compute_dtype(self, dtype):
         if isinstance(dtype, str):

@@ -120,3 +120,47 @@ def test_joints_mse_without_target_weight():
     assert rel_err(out.grad, gref) < 1e-5
     lw = JointsMSELoss(use_target_weight=True)(out.detach(), tgt, tw)
     assert abs(float(lw) - float(O.joints_mse_loss(out.detach(), tgt, tw))) < 1e-6
+
+
+def test_parameter_gradients_accumulate_like_autograd():
+    """VERDICT round 2 (missing 6): the reference module is a plain autograd module (model/multitasknet.py:24-29), so
+    two backward passes without zero_grad ADD (Lightning's accumulate_grad_batches), zero_grad(set_to_none=False)
+    zeroes in place and the next backward starts from zero, set_to_none=True starts from None, and a gradient that
+    was already in p.grad is kept."""
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=12)
+    b1, b2 = O.synthetic_batch(2, 32, seed=15), O.synthetic_batch(2, 32, seed=16)
+    m = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+
+    def grads_of(batch):
+        img, label, target, tw = batch
+        c, h, _ = m(img)
+        O.total_loss(c, h, label, target, tw)[0].backward()
+        return torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+
+    def running_stats():
+        return {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+
+    g1 = grads_of(b1)
+    m.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in m.parameters())
+    g2 = grads_of(b2)
+    assert not torch.equal(g1, g2)
+    g12 = grads_of(b1)                                    # no zero_grad in between: accumulates
+    assert rel_err(g12, g1 + g2) < 1e-5
+    m.zero_grad(set_to_none=False)                        # zeroed in place, p.grad stays our view
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in m.parameters())
+    assert rel_err(grads_of(b1), g1) < 1e-5
+    # a foreign gradient already present on one parameter is kept; the others start fresh
+    m.zero_grad(set_to_none=True)
+    first = next(m.parameters())
+    first.grad = torch.ones_like(first)
+    g = grads_of(b2)
+    n0 = first.numel()
+    assert rel_err(g[:n0], g2[:n0] + 1.0) < 1e-5 and rel_err(g[n0:], g2[n0:]) < 1e-5
+    # an optimizer sees ordinary .grad tensors
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    w0 = first.detach().clone()
+    opt.step()
+    assert rel_err(first.detach(), w0 - 0.1 * g[:n0].view_as(w0)) < 1e-6
