@@ -204,3 +204,23 @@ def test_stem_backward_with_dc_offset_inputs(kind, dtype, tol):
     print(f"[{kind}/{dtype}] stem {stem}, worst {worst}")
     assert max(stem.values()) < tol, stem
     assert worst[0] < 2.5 * tol, worst
+
+
+@pytest.mark.parametrize("B", [5, 33])
+def test_odd_batch_sizes_bf16x3_vs_fp32(B):
+    """Ragged tiles in the split-bf16 mode (its own tile choices: 2x2-wave weight-gradient tiles, pre-split weights):
+    outputs / losses at 1e-3 and every parameter gradient at 5e-3 of the exact-f32 mode, reproducible bit for bit."""
+    be, _, m32 = _model(192, torch.float32, seed=3)
+    _, _, mx3 = _model(192, "bf16x3", seed=3)
+    batch = synthetic_batch(B, (192, 192), 21, 19, be.device, 5)
+    s32, sx3 = TrainStep(m32, B, lr=1e-3), TrainStep(mx3, B, lr=1e-3)
+    s32._fwd_bwd(*batch)
+    sx3._fwd_bwd(*batch)
+    be.sync()
+    assert rel_err(sx3.eng.losses, s32.eng.losses) < 1e-3
+    assert rel_err(sx3.eng.logits, s32.eng.logits) < 1e-3 and rel_err(sx3.eng.hm, s32.eng.hm) < 1e-3
+    worst = max((rel_err(p._mtn_grad, q._mtn_grad), k) for (k, p), (_, q) in zip(mx3.named_parameters(), m32.named_parameters()))
+    assert worst[0] < 5e-3, worst
+    g = mx3.flat_grads.clone()
+    sx3._fwd_bwd(*batch)
+    assert torch.equal(mx3.flat_grads, g)

@@ -199,6 +199,15 @@ def test_train_steps_fp32_gpu(golden_dir):
 
 
 @pytest.mark.gpu
+def test_train_steps_bf16x3_gpu(golden_dir):
+    """the fused step (AdamW included) in the split-bf16 mode against the oracle's train step: losses of three
+    consecutive steps at 1e-3 / 2e-3, weights by norm and by the per-element budget; also replayed from a hipGraph"""
+    _train_steps(Backend("hip"), "config1_b4_s192", golden_dir, "bf16x3", 1, 1e-3)
+    _train_steps(Backend("hip"), "small_b2_s64", golden_dir, "bf16x3", 3, 2e-3)
+    _train_steps(Backend("hip"), "small_b2_s64", golden_dir, "bf16x3", 3, 2e-3, use_graph=True)
+
+
+@pytest.mark.gpu
 def test_train_steps_graph_gpu(golden_dir):
     """the hipGraph replay path gives the same step as the eager one"""
     _train_steps(Backend("hip"), "small_b2_s64", golden_dir, torch.float32, 3, 2e-3, use_graph=True)
