@@ -40,6 +40,32 @@ __global__ __launch_bounds__(1024) void rowblock_sum_kernel(const float* __restr
     }
 }
 
+// The same for a TABLE of slabs in one launch (grid.z = job): the parameter-gradient slabs of the ViT backward -- LayerNorm
+// weight / bias, Linear biases -- are leaves of the dependency graph, so the plan leaves them unreduced and folds all of
+// them with two launches of this kernel at the end of the bucket (level 1: 128 rows per block into the slab's scratch tail,
+// level 2: the rest into the gradient) instead of two launches per slab.  job = {in, out, rows, W, ld, rows_per_block}.
+struct ColJob { const float* in; float* out; int rows, W, ld, rows_per_block; };
+__global__ __launch_bounds__(1024) void rowblock_sum_grouped_kernel(const ColJob* __restrict__ jobs) {
+    __shared__ float red[kLanes][64];
+    const ColJob j = jobs[blockIdx.z];
+    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * j.rows_per_block;
+    if (blockIdx.x * 64 >= j.W || r0 >= j.rows) return;           // (workgroup-uniform: the grid is the largest job's)
+    int r1 = r0 + j.rows_per_block;
+    if (r1 > j.rows) r1 = j.rows;
+    float s = 0.f;
+    if (c < j.W)
+        for (int r = r0 + tl; r < r1; r += kLanes) s += j.in[(long)r * j.ld + c];
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0 && c < j.W) {
+        float t = 0.f;
+        MTN_UNROLL for (int q = 0; q < kLanes; ++q) t += red[q][cl];
+        j.out[(long)blockIdx.y * j.W + c] = t;
+    }
+}
+
 // block = 16 row-lanes x 64 channels; returns (sum over R rows of part[r][which][c]) in double
 __device__ __forceinline__ void sum2_rows(const float* __restrict__ part, int R, int C, int c, bool valid,
                                           double& s0, double& s1) {
@@ -361,6 +387,26 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
                    (float*)a.dy, a.lddy, (float*)a.dres, a.lddres, (const float*)a.extra, a.ldextra, a.M, a.C, a.act);
     return mtn_check_launch("bn_bwd_apply");
 }
+
+// Grouped form of mtn_colsum_ld_run: jobs int64 [njobs][6] on the device = {slab pointer, out pointer, rows, W, ld, 0}.  The
+// host side gives the (largest) extents; the table for the second level is derived by the first launch's geometry: level 1
+// writes job i's folded rows behind its slab (as fold_rows does), so the caller passes BOTH tables (see ops.colsum_grouped).
+int mtn_colsum_grouped_run(const void* jobs_l1, int n1, int max_w1, int max_rowblocks1, const void* jobs_l2, int n2, int max_w2,
+                           hipStream_t stream) {
+    MTN_REQUIRE(n1 >= 0 && n2 > 0 && jobs_l2, "colsum_grouped: bad tables");
+    if (n1 > 0) {
+        MTN_REQUIRE(jobs_l1 && max_w1 > 0 && max_rowblocks1 > 0, "colsum_grouped: bad level-1 table");
+        MTN_LAUNCH(rowblock_sum_grouped_kernel, dim3(mtn_cdiv(max_w1, 64), max_rowblocks1, n1), dim3(1024), 0, stream,
+                   reinterpret_cast<const ColJob*>(jobs_l1));
+        int rc = mtn_check_launch("colsum_grouped_l1");
+        if (rc) return rc;
+    }
+    MTN_LAUNCH(rowblock_sum_grouped_kernel, dim3(mtn_cdiv(max_w2, 64), 1, n2), dim3(1024), 0, stream,
+               reinterpret_cast<const ColJob*>(jobs_l2));
+    return mtn_check_launch("colsum_grouped_l2");
+}
+int mtn_fold_rows_per_block(void) { return kRowsPerBlock; }
+int mtn_fold_direct_rows(void) { return kDirectRows; }
 
 // generic ordered column sum of an f32 slab: out[c] = sum_r in[r][c]  (bias / LayerNorm affine grads)
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream) {

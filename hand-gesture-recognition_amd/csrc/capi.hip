@@ -148,7 +148,7 @@ int mtn_linear_gelu_bwd_tiles(int M, int N, int K) { return mtn_igemm_tiles_m(M,
 
 int mtn_linear_gelu_bwd(const void* dh, int lddh, const void* wt, const void* a, int lda, void* da, int ldda,
                         float* partial, int tiles, float* dbias, int dtype, int M, int N, int K, void* stream) {
-    MTN_REQUIRE(a && partial && dbias, "linear_gelu_bwd: null operand");
+    MTN_REQUIRE(a && partial, "linear_gelu_bwd: null operand");
     IgemmArgs p{};
     p.A = dh; p.Wp = wt; p.Out = da; p.lda = lddh; p.ldc = ldda;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.KH = p.KW = 1;
@@ -158,6 +158,7 @@ int mtn_linear_gelu_bwd(const void* dh, int lddh, const void* wt, const void* a,
     p.stats = partial; p.stats_rows = tiles;
     const int rc = mtn_igemm_run(p, dtype, (hipStream_t)stream);
     if (rc) return rc;
+    if (!dbias) return MTN_OK;                            // the caller folds the slab later (mtn_colsum_grouped)
     return mtn_colsum_ld_run(partial, tiles, N, 2 * N, dbias, (hipStream_t)stream);    // the sum half of each [2][N] row
 }
 
@@ -286,6 +287,13 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
     return mtn_bn_bwd_run(a, mtn_storage_dtype(dtype), (hipStream_t)stream);
 }
 
+int mtn_colsum_rows_per_block(void) { return mtn_fold_rows_per_block(); }
+int mtn_colsum_direct_rows(void) { return mtn_fold_direct_rows(); }
+int mtn_colsum_grouped(const void* jobs_l1, int n1, int max_w1, int max_rowblocks1, const void* jobs_l2, int n2, int max_w2,
+                       void* stream) {
+    return mtn_colsum_grouped_run(jobs_l1, n1, max_w1, max_rowblocks1, jobs_l2, n2, max_w2, (hipStream_t)stream);
+}
+
 int mtn_tokens_fwd(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B, int P, void* stream) {
     return mtn_tokens_fwd_run(feat, pos, cls, tok, mtn_storage_dtype(dtype), B, P, (hipStream_t)stream);
 }
@@ -297,6 +305,7 @@ int mtn_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* b
     return mtn_ln_fwd_run(x, ldx, gamma, beta, y, ldy, mean_rstd, mtn_storage_dtype(dtype), M, eps, (hipStream_t)stream);
 }
 int mtn_rowslab_rows(int M) { return mtn_reduce_rows_needed(mtn_rowslab_blocks(M)); }
+int mtn_rowslab_producer_rows(int M) { return mtn_rowslab_blocks(M); }
 int mtn_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma,
                       const void* dres, int lddres, void* dx, int lddx, float* partial, float* dgamma_dbeta, int dtype,
                       int M, void* stream) {

@@ -95,6 +95,10 @@ int mtn_bn_bwd_blocks(int M);
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream);
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream);
 int mtn_colsum_ld_run(float* slab, int rows, int W, int ld, float* out, hipStream_t stream);
+int mtn_colsum_grouped_run(const void* jobs_l1, int n1, int max_w1, int max_rowblocks1, const void* jobs_l2, int n2, int max_w2,
+                           hipStream_t stream);
+int mtn_fold_rows_per_block(void);
+int mtn_fold_direct_rows(void);
 
 int mtn_conv1_tiles(long M);
 int mtn_conv1_fwd_run(const float* x, const void* w, void* y, float* stats, int dtype, int B, int H, int W,

@@ -320,6 +320,7 @@ int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float
                    gamma, (const float*)dres, lddres, (float*)dx, lddx, partial, M, kLnRows);
     int rc = mtn_check_launch("ln_bwd");
     if (rc) return rc;
+    if (!dgamma_dbeta) return MTN_OK;                     // the caller folds the slab later (mtn_colsum_grouped)
     return mtn_colsum_run(partial, blocks, 2 * DIM, dgamma_dbeta, stream);   // [dgamma | dbeta]
 }
 
@@ -345,6 +346,7 @@ int mtn_bias_grad_run(const void* dy, int lddy, float* partial, float* dbias, in
         MTN_LAUNCH(colsum_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, partial, M, kLnRows);
     int rc = mtn_check_launch("bias_grad");
     if (rc) return rc;
+    if (!dbias) return MTN_OK;                            // the caller folds the slab later (mtn_colsum_grouped)
     return mtn_colsum_run(partial, blocks, DIM, dbias, stream);
 }
 

@@ -73,6 +73,9 @@ class Engine:
         # data gradients pre-reduce the BatchNorm backward of the unit they feed (MTN_FUSE_BN_BWD=0: two-pass backward)
         self.fuse_bn_bwd = os.environ.get("MTN_FUSE_BN_BWD", "1") != "0"
         self.fuse_gelu_bwd = os.environ.get("MTN_FUSE_GELU_BWD", "1") != "0"     # (0: three launches per FeedForward)
+        # LayerNorm / bias gradients of the ViT are leaves: their partial-sum slabs are folded by ONE grouped call at the end
+        # of the bucket instead of two launches per slab (MTN_DEFER_LEAF_SUMS=0: fold each one where it is produced)
+        self.defer_leaf_sums = os.environ.get("MTN_DEFER_LEAF_SUMS", "1") != "0"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -245,6 +248,20 @@ class Engine:
         mlp = self.layers[0]["fc1"].out_features
         self.gelu_tiles = ops.linear_gelu_bwd_tiles(Mt, mlp, D)
         self.gelu_part = self._f32(ops.slab_rows(self.gelu_tiles), 2, mlp)
+        self.leaf_plan = None
+        if self.defer_leaf_sums and self.fuse_gelu_bwd:
+            # one slab per producer (they stay unreduced until the end of the ViT backward) + the table of folds
+            prod, jobs = ops.rowslab_producer_rows(Mt), []
+            for L in self.layers:
+                at, ff = L["attn"], L["ff"]
+                L["p_ln1"], L["p_ln2"] = self._f32(ops.rowslab_rows(Mt), 2 * D), self._f32(ops.rowslab_rows(Mt), 2 * D)
+                L["p_b2"] = self._f32(ops.rowslab_rows(Mt), D)
+                L["p_gelu"] = self._f32(ops.slab_rows(self.gelu_tiles), 2, mlp)
+                jobs.append((L["p_ln1"], prod, 2 * D, 2 * D, self._pair(at.norm.weight, at.norm.bias)))
+                jobs.append((L["p_ln2"], prod, 2 * D, 2 * D, self._pair(ff.net[0].weight, ff.net[0].bias)))
+                jobs.append((L["p_b2"], prod, D, D, self._g(ff.net[4].bias)))
+                jobs.append((L["p_gelu"], self.gelu_tiles, mlp, 2 * mlp, self._g(ff.net[1].bias)))      # the sum half of [2][mlp] rows
+            self.leaf_plan = ops.ColsumPlan(jobs)
         self.attn = self._f32(B, self.heads, self.N, self.N)
         self.logits = self._f32(B, self.C)
         self.hm = self._f32(B, self.J, 4 * self.fh, 4 * self.fw)
@@ -498,32 +515,39 @@ class Engine:
             at, ff = L["attn"], L["ff"]
             fc1, fc2, ln2 = ff.net[1], ff.net[4], ff.net[0]
             # x2 = fc2(gelu(fc1(LN(x1)))) + x1
-            ops.bias_grad(Gm, self.row_part, g(fc2.bias))
+            defer = self.leaf_plan is not None
+            if defer:
+                ops.bias_grad(Gm, L["p_b2"], None)
+            else:
+                ops.bias_grad(Gm, self.row_part, g(fc2.bias))
             ops.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
             if self.fuse_gelu_bwd:
                 # d a = (G @ fc2.W) * gelu'(a) and fc1's bias gradient (its column sums) in one launch
-                ops.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, self.gelu_part, self.gelu_tiles, g(fc1.bias))
+                ops.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
+                                    None if defer else g(fc1.bias))
             else:
                 ops.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
                 ops.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
                 ops.bias_grad(self.t_b, self.row_part, g(fc1.bias))
             ops.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
             ops.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
-            ops.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, self.row_part,
-                              self._pair(ln2.weight, ln2.bias), dres=Gm)
+            ops.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, L["p_ln2"] if defer else self.row_part,
+                              None if defer else self._pair(ln2.weight, ln2.bias), dres=Gm)
             # x1 = to_out(attention(LN(x0))) + x0
             ops.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
             ops.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
             ops.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
             ops.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
             ops.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
-            ops.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, self.row_part,
-                              self._pair(at.norm.weight, at.norm.bias), dres=Gm)
+            ops.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
+                              None if defer else self._pair(at.norm.weight, at.norm.bias), dres=Gm)
         ops.tokens_bwd(G, self.g_feat, g(dec.cls_token))
         up, last = self.u_proj, self.stages[-1]
         gf = self.g_feat.view(self.B, self.fh, self.fw, D)
         ops.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
         self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
+        if self.leaf_plan is not None:
+            self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches
         self._ready("head")
         self.backbone_backward(last["g_out"])
 

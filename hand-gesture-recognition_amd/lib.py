@@ -50,8 +50,12 @@ _PROTOS = {
     "mtn_tokens_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_layernorm_fwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _f, _vp],
     "mtn_rowslab_rows": [_i],
+    "mtn_rowslab_producer_rows": [_i],
     "mtn_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "mtn_gelu_bwd": [_vp, _vp, _vp, _i, _ll, _vp],
+    "mtn_colsum_rows_per_block": [],
+    "mtn_colsum_direct_rows": [],
+    "mtn_colsum_grouped": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "mtn_bias_grad": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "mtn_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "mtn_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
@@ -74,7 +78,7 @@ _PROTOS = {
     "mtn_debug_read": [_i, _vp, _sz],
 }
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}
-_STATUS_FREE = {"mtn_abi_version", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
+_STATUS_FREE = {"mtn_abi_version", "mtn_colsum_rows_per_block", "mtn_colsum_direct_rows", "mtn_rowslab_producer_rows", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
                 "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",

@@ -149,12 +149,14 @@ def linear_gelu_bwd(dh, wt, a, da, partial, tiles, dbias):
     M = dh.numel() // K
     if a.shape != da.shape or a.dtype != da.dtype or dh.dtype != da.dtype:
         raise ValueError("linear_gelu_bwd: a and da must have one shape and dtype")
-    if partial.dtype != torch.float32 or partial.numel() < slab_rows(tiles) * 2 * N or dbias.numel() != N or dbias.dtype != torch.float32:
-        raise ValueError("linear_gelu_bwd: partial slab / dbias size")
+    if partial.dtype != torch.float32 or partial.numel() < slab_rows(tiles) * 2 * N:
+        raise ValueError("linear_gelu_bwd: partial slab size")
+    if dbias is not None and (dbias.numel() != N or dbias.dtype != torch.float32):
+        raise ValueError("linear_gelu_bwd: dbias size")
     hp, ldh = _rows(dh)
     ap, lda = _rows(a)
     dp, ldd = _rows(da)
-    lib.call("mtn_linear_gelu_bwd", hp, ldh, wt.data_ptr(), ap, lda, dp, ldd, partial.data_ptr(), tiles, dbias.data_ptr(),
+    lib.call("mtn_linear_gelu_bwd", hp, ldh, wt.data_ptr(), ap, lda, dp, ldd, partial.data_ptr(), tiles, _p(dbias),
              dtype_code(dh), M, N, K, _stream(dh))
 
 
@@ -323,7 +325,7 @@ def layernorm_bwd(dy, x, mean_rstd, gamma, dx, partial, dgamma_dbeta, dres=None)
     rp, ldr = _rows(dres) if dres is not None else (0, 0)
     M = x.numel() // x.shape[-1]
     lib.call("mtn_layernorm_bwd", dyp, lddy, xp, ldx, mean_rstd.data_ptr(), gamma.data_ptr(), rp, ldr,
-             dxp, lddx, partial.data_ptr(), dgamma_dbeta.data_ptr(), dtype_code(x), M, _stream(x))
+             dxp, lddx, partial.data_ptr(), _p(dgamma_dbeta), dtype_code(x), M, _stream(x))
 
 
 def gelu_bwd(dh, a, da):
@@ -334,7 +336,51 @@ def gelu_bwd(dh, a, da):
 def bias_grad(dy, partial, dbias):
     dyp, lddy = _rows(dy)
     M = dy.numel() // dy.shape[-1]
-    lib.call("mtn_bias_grad", dyp, lddy, partial.data_ptr(), dbias.data_ptr(), dtype_code(dy), M, _stream(dy))
+    lib.call("mtn_bias_grad", dyp, lddy, partial.data_ptr(), _p(dbias), dtype_code(dy), M, _stream(dy))
+
+
+def rowslab_producer_rows(M):
+    return lib.call("mtn_rowslab_producer_rows", M)
+
+
+class ColsumPlan:
+    """Deferred parameter-gradient folds (include/mtn.h: mtn_colsum_grouped): the producers were called with a null
+    gradient pointer and left their partial sums in their slabs; ``run()`` folds ALL of them with two launches.
+    jobs: list of (slab f32 tensor, producer rows, W, ld, out f32 tensor)."""
+
+    def __init__(self, jobs):
+        import numpy as np
+        rpb, direct = lib.call("mtn_colsum_rows_per_block"), lib.call("mtn_colsum_direct_rows")
+        rec = np.dtype([("inp", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("W", "<i4"), ("ld", "<i4"), ("rpb", "<i4")])
+        l1, l2 = [], []
+        for slab, rows, W, ld, out in jobs:
+            # (``out`` may be the first tensor of an adjacent (weight, bias) pair in the flat gradient buffer: W spans both)
+            if slab.dtype != torch.float32 or out.dtype != torch.float32:
+                raise ValueError("ColsumPlan: f32 slabs / outputs only")
+            if rows > direct:
+                R = (rows + rpb - 1) // rpb
+                if R > direct:
+                    raise ValueError(f"ColsumPlan: {rows} rows need more than two fold levels")
+                if slab.numel() < rows * ld + R * W:
+                    raise ValueError("ColsumPlan: the slab has no scratch tail for its folded rows (allocate slab_rows(...) rows)")
+                scratch = slab.data_ptr() + 4 * rows * ld
+                l1.append((slab.data_ptr(), scratch, rows, W, ld, rpb))
+                l2.append((scratch, out.data_ptr(), R, W, W, R))
+            else:
+                l2.append((slab.data_ptr(), out.data_ptr(), rows, W, ld, rows))
+        dev = jobs[0][0].device
+        self.keep = [j[0] for j in jobs] + [j[4] for j in jobs]          # the tables hold raw pointers into these
+        mk = lambda recs: torch.from_numpy(np.array(recs, dtype=rec).view(np.uint8).copy()).to(dev) if recs else None
+        self.t1, self.t2 = mk(l1), mk(l2)
+        self.n1, self.n2 = len(l1), len(l2)
+        self.w1 = max((r[3] for r in l1), default=0)
+        self.rb1 = max(((r[2] + rpb - 1) // rpb for r in l1), default=0)
+        self.w2 = max(r[3] for r in l2)
+        self.dev = dev
+
+    def run(self):
+        lib.call("mtn_colsum_grouped", _p(self.t1), self.n1, self.w1, self.rb1, self.t2.data_ptr(), self.n2, self.w2,
+                 _stream(self.t2))
 
 
 def attention_fwd(qkv, out, lse, attn, B, N, H, D, scale):

@@ -184,6 +184,8 @@ int mtn_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* b
                       float* mean_rstd, int dtype, int M, float eps, void* stream);
 /* rows of the f32 partial slab ([rows][512] for LayerNorm, [rows][256] for bias gradients) */
 int mtn_rowslab_rows(int M);
+/* ... of which the kernels themselves write the first mtn_rowslab_producer_rows(M) (the rest is folding scratch) */
+int mtn_rowslab_producer_rows(int M);
 /* dx = LN'(dy) [+ dres] (dx may alias dres); dgamma_dbeta f32 [2][256] (weight grad, then bias grad) */
 int mtn_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd,
                       const float* gamma, const void* dres, int lddres, void* dx, int lddx,
@@ -199,6 +201,18 @@ int mtn_linear_gelu_bwd_tiles(int M, int N, int K);
 int mtn_linear_gelu_bwd(const void* dh, int lddh, const void* wt, const void* a, int lda, void* da,
                         int ldda, float* partial, int tiles, float* dbias, int dtype, int M, int N,
                         int K, void* stream);
+/* Deferred parameter-gradient folds.  mtn_layernorm_bwd (dgamma_dbeta = NULL), mtn_bias_grad and mtn_linear_gelu_bwd
+ * (dbias = NULL) then leave their per-workgroup partial sums in `partial` -- these gradients are leaves of the backward
+ * graph -- and ONE call folds any number of such slabs: out[c] = sum over rows of in[r][c], in a fixed order (two levels:
+ * blocks of mtn_colsum_rows_per_block() rows into the slab's scratch tail, then the rest; slabs of at most
+ * mtn_colsum_direct_rows() rows skip level 1).  jobs_l1 / jobs_l2: device tables, one 32-byte record per slab:
+ * {const float* in; float* out; int32 rows, W, ld, rows_per_block}; the level-1 record of a slab writes
+ * out = in + rows*ld (its scratch tail, [ceil(rows / rpb)][W] dense), its level-2 record reads that.  max_w* /
+ * max_rowblocks1: the largest W / row-block count of a table (grid extents).  Replaces two launches per slab by two in all. */
+int mtn_colsum_rows_per_block(void);
+int mtn_colsum_direct_rows(void);
+int mtn_colsum_grouped(const void* jobs_l1, int n1, int max_w1, int max_rowblocks1, const void* jobs_l2, int n2,
+                       int max_w2, void* stream);
 /* dbias[256] = column sums of dy[M][256] */
 int mtn_bias_grad(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, void* stream);
 
