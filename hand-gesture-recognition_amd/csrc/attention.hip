@@ -317,33 +317,41 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
         const float c2 = scale * 1.4426950408889634f;
         const float lq2 = (qok ? lse[(long)bh * N + q] : 0.f) * 1.4426950408889634f;
         if (qok && g == 0) delta[(long)bh * N + q] = dl;
-        f32x4_t ds[MAXT];
-        MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
-            if (FULL || kt < nkt) {
-                RowOp<T> kf, vf;
-                kf.load(sK + (kt * 16 + li) * PITCH, true, g);
-                vf.load(sV + (kt * 16 + li) * PITCH, true, g);
-                const f32x4_t s = mma32(kf, qf, zero4());
-                const f32x4_t dp = mma32(vf, dof, zero4());
-                MTN_UNROLL for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f_(fmaf(s[r], c2, -lq2));
-                    ds[kt][r] = p * (dp[r] - dl) * scale;
-                }
-                if (FULL ? (kt >= MAXT - 2) : (kt * 16 + 16 > N)) {   // tiles that can hold padded keys: exp(0 - lse) may overflow
-                    MTN_UNROLL for (int r = 0; r < 4; ++r)
-                        if (kt * 16 + 4 * g + r >= N) ds[kt][r] = 0.f;
-                }
-            }
-            // groups of four tiles: enough independent MFMAs in flight, without hoisting all 2 x MAXT score tiles into
-            // registers at once (the fully unrolled form spilled 100-700 registers)
-            if (FULL && (kt & 3) == 3) MTN_SCHED_FENCE();
-        }
+        // dQ^T = K^T dS^T accumulates over the keys, so the score tiles need not all be alive at once (unlike the forward,
+        // whose softmax needs the whole row): groups of GK key tiles -- 2 GK independent MFMAs in flight, their dS, then the
+        // GK / 2 pair products into the two accumulators.  Registers stay at GK tiles whatever the sequence length, which
+        // is what lets the 38-tile (577-token) form run with a compile-time tile count too.
+        constexpr int GK = 8;
         f32x4_t d0 = zero4(), d1 = zero4();
-        MTN_UNROLL for (int pr = 0; pr < MAXT / 2; ++pr) {
-            if (FULL || 2 * pr < nkt) {
-                d0 = acc_mma(sK + pr * 32 * PITCH, PITCH, ds[2 * pr], ds[2 * pr + 1], d0, lane);
-                d1 = acc_mma(sK + pr * 32 * PITCH + 16, PITCH, ds[2 * pr], ds[2 * pr + 1], d1, lane);
+        MTN_UNROLL for (int k0 = 0; k0 < MAXT; k0 += GK) {
+            f32x4_t ds[GK];
+            MTN_UNROLL for (int u = 0; u < GK; ++u) {
+                const int kt = k0 + u;
+                ds[u] = zero4();
+                if (kt < MAXT && (FULL || kt < nkt)) {
+                    RowOp<T> kf, vf;
+                    kf.load(sK + (kt * 16 + li) * PITCH, true, g);
+                    vf.load(sV + (kt * 16 + li) * PITCH, true, g);
+                    const f32x4_t s = mma32(kf, qf, zero4());
+                    const f32x4_t dp = mma32(vf, dof, zero4());
+                    MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                        const float p = exp2f_(fmaf(s[r], c2, -lq2));
+                        ds[u][r] = p * (dp[r] - dl) * scale;
+                    }
+                    if (FULL ? (kt >= MAXT - 2) : (kt * 16 + 16 > N)) {   // tiles that can hold padded keys: exp(0 - lse) may overflow
+                        MTN_UNROLL for (int r = 0; r < 4; ++r)
+                            if (kt * 16 + 4 * g + r >= N) ds[u][r] = 0.f;
+                    }
+                }
             }
+            MTN_UNROLL for (int u = 0; u < GK; u += 2) {
+                const int pr = (k0 + u) / 2;                       // (the padded tile count is even: pairs are complete)
+                if (k0 + u < MAXT && (FULL || 2 * pr < nkt)) {
+                    d0 = acc_mma(sK + pr * 32 * PITCH, PITCH, ds[u], ds[u + 1], d0, lane);
+                    d1 = acc_mma(sK + pr * 32 * PITCH + 16, PITCH, ds[u], ds[u + 1], d1, lane);
+                }
+            }
+            if (FULL) MTN_SCHED_FENCE();
         }
         if (qok) {
             T* dp = dqkv + (row0 + q) * ld + h * HD + 4 * g;
@@ -467,7 +475,8 @@ int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
     } while (0)
     if (NP / 16 == 10) MTN_ATTN_DQ(10, true);
     else if (NP / 16 < 10) MTN_ATTN_DQ(10, false);
-    else MTN_ATTN_DQ(38, false);      // (38 tiles fully unrolled: ds[38] + the tile group in flight spill; the guarded form does not)
+    else if (NP / 16 == 38) MTN_ATTN_DQ(38, true);
+    else MTN_ATTN_DQ(38, false);
 #undef MTN_ATTN_DQ
     int rc = mtn_check_launch("attn_bwd_dq");
     if (rc) return rc;
