@@ -18,6 +18,7 @@
 static int g_wgrad_tile = 0;     // debug key 7: 64 forces 64x64 tiles
 static int g_wgrad_dma = 1;      // LDS-DMA pipeline (debug key 5 selects the register-staged one)
 static int g_wgrad_slots = 0;    // debug key 10: workgroups per launch the pixel split aims at (0 = per-tile default)
+static int g_x3_wgrad_sep = 1;   // debug key 20: 0 = the split-bf16 128x128 weight gradient keeps the one-array pipeline
 
 namespace {
 
@@ -356,7 +357,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
 // pointer fixed outside the loop): measured 5 % faster on the 8-wave 128x128 tile, and slower on the
 // 128x64 tile (the second copy of the loader state costs it 50 registers and a resident workgroup),
 // so only the former uses it.
-template <class T, int BN, int BC, int WGM, int WGN>
+// SEP: the two stages are two DISTINCT __shared__ objects: hipcc then knows that the LDS-DMA of step st+1 cannot alias the
+// fragment reads of step st and drops the `s_waitcnt vmcnt(0)` it otherwise puts in front of the first fragment read (seen
+// in the ISA of the one-array form: a workgroup then never overlaps its own DMA with its own MFMAs).  In bf16 that overlap
+// measured slower (round 2: the co-resident workgroups already cover each other and the in-flight DMA contends with the
+// fragment reads); in the split-bf16 mode the multiply phase of a step is 3-4x longer and worth hiding the DMA under.
+template <class T, int BN, int BC, int WGM, int WGN, bool SEP = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -369,9 +375,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) 
     constexpr int FM = WM / 16, FN = WN / 16;
     static_assert(BMR % (RPBY * NW) == 0 && BMR % (RPBX * NW) == 0, "DMA mapping");
 
+    constexpr int STAGE = 128 / (int)sizeof(T) * (BN + BC);       // elements of one stage: [BMR][BN] dY then [BMR][BC] X
+    __shared__ __attribute__((aligned(16))) T sSep0[SEP ? STAGE : 1];
+    __shared__ __attribute__((aligned(16))) T sSep1[SEP ? STAGE : 1];
     MTN_DYN_SMEM(smem);
-    T* const sStage0 = reinterpret_cast<T*>(smem);               // [BMR][BN] dY then [BMR][BC] X
-    T* const sStage1 = sStage0 + BMR * (BN + BC);
+    T* const sStage0 = SEP ? sSep0 : reinterpret_cast<T*>(smem);
+    T* const sStage1 = SEP ? sSep1 : sStage0 + STAGE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
 
@@ -835,6 +844,12 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
     mtn_set_max_lds(attr, &wgrad_dma_kernel<T, BN, BC, WGM, WGN>, lds);
 #endif
     const int tiles = (p.N / BN) * (p.K / BC);
+    if constexpr (std::is_same<T, f32x3_t>::value) {
+        if (BN == 128 && BC == 128 && g_x3_wgrad_sep) {          // split-bf16 mode: separate stages (see wgrad_dma2_kernel)
+            MTN_LAUNCH((wgrad_dma2_kernel<T, BN, BC, WGM, WGN, true>), dim3(tiles * p.splits), dim3(NT), 0, stream, p);
+            return mtn_check_launch("wgrad_dma2_sep");
+        }
+    }
     if (BN == 128 && BC == 128 && WGM * WGN == 8) {
 #ifndef MTN_EMU
         static MtnLdsAttr attr2;
@@ -926,6 +941,7 @@ void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
 void mtn_wgrad_set_slots(int n) { g_wgrad_slots = n > 0 ? n : 0; }
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
+void mtn_wgrad_set_x3_sep(int on) { g_x3_wgrad_sep = on ? 1 : 0; }
 
 // tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
 static void wgrad_tile(int N, int Cin, int* bn, int* bc) {
