@@ -18,7 +18,8 @@
 static int g_wgrad_tile = 0;     // debug key 7: 64 forces 64x64 tiles
 static int g_wgrad_dma = 1;      // LDS-DMA pipeline (debug key 5 selects the register-staged one)
 static int g_wgrad_slots = 0;    // debug key 10: workgroups per launch the pixel split aims at (0 = per-tile default)
-static int g_x3_wgrad_sep = 1;   // debug key 20: 0 = the split-bf16 128x128 weight gradient keeps the one-array pipeline
+static int g_x3_wgrad_sep = 0;   // debug key 20: 1 = separate LDS stages for the split-bf16 128x128 weight gradient, 2 = in every mode
+                                 // (measured SLOWER: 22.1 vs 21.25 ms per bf16x3 step -- DESIGN.md 7d)
 
 namespace {
 
@@ -359,9 +360,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
 // so only the former uses it.
 // SEP: the two stages are two DISTINCT __shared__ objects: hipcc then knows that the LDS-DMA of step st+1 cannot alias the
 // fragment reads of step st and drops the `s_waitcnt vmcnt(0)` it otherwise puts in front of the first fragment read (seen
-// in the ISA of the one-array form: a workgroup then never overlaps its own DMA with its own MFMAs).  In bf16 that overlap
-// measured slower (round 2: the co-resident workgroups already cover each other and the in-flight DMA contends with the
-// fragment reads); in the split-bf16 mode the multiply phase of a step is 3-4x longer and worth hiding the DMA under.
+// in the ISA of the one-array form: a workgroup then never overlaps its own DMA with its own MFMAs).  That overlap measured
+// slower in bf16 (round 2) AND in the split-bf16 mode (round 3: 22.1 vs 21.25 ms per step): the co-resident workgroups
+// already cover each other, and DMA in flight contends with the fragment reads.  Kept behind debug key 20.
 template <class T, int BN, int BC, int WGM, int WGN, bool SEP = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) {
     constexpr int NW = WGM * WGN;
@@ -850,6 +851,10 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
             return mtn_check_launch("wgrad_dma2_sep");
         }
     }
+    if (BN == 128 && BC == 128 && WGM * WGN == 8 && g_x3_wgrad_sep == 2) {      // (experiment: separate stages in every mode)
+        MTN_LAUNCH((wgrad_dma2_kernel<T, BN, BC, WGM, WGN, true>), dim3(tiles * p.splits), dim3(NT), 0, stream, p);
+        return mtn_check_launch("wgrad_dma2_sep");
+    }
     if (BN == 128 && BC == 128 && WGM * WGN == 8) {
 #ifndef MTN_EMU
         static MtnLdsAttr attr2;
@@ -941,7 +946,7 @@ void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
 void mtn_wgrad_set_slots(int n) { g_wgrad_slots = n > 0 ? n : 0; }
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
-void mtn_wgrad_set_x3_sep(int on) { g_x3_wgrad_sep = on ? 1 : 0; }
+void mtn_wgrad_set_x3_sep(int on) { g_x3_wgrad_sep = (on == 1 || on == 2) ? on : 0; }
 
 // tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
 static void wgrad_tile(int N, int Cin, int* bn, int* bc) {
