@@ -571,6 +571,11 @@ void igemm_kernel(IgemmArgs p) {
             const int cur = kt & 1;
             STAMP(t0);
             if (kt + 1 < KT) dma_tiles(kt + 1, cur ^ 1);
+#ifndef MTN_EMU
+            // experiment (debug key 8 = 5): drain the DMA just issued before this step's fragment reads, i.e. give up the
+            // overlap of a workgroup's own DMA with its own MFMAs the way wgrad's one-array pipeline does by accident
+            if (p.dbg == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             STAMP(t1);
             compute(cur);
             STAMP(t2);
