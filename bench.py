@@ -144,7 +144,7 @@ def igemm_roofline(step, batch):
     # averaged over all instances of the template
     traffic, src = None, None
     import re
-    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic.*\.json$", n)]
+    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic_v\d+\.json$", n)]   # (not the configs' files)
     # newest collection: highest round, then highest version (r02_..._v3 > r02_..._v2 > r01_..._v10)
     cands.sort(key=lambda n: [int(x) for x in re.findall(r"\d+", n)], reverse=True)
     for name in cands:
