@@ -92,7 +92,7 @@ void igemm_kernel(IgemmArgs p) {
     constexpr bool WIN = STAGES == 5 || STAGES == 6;
     constexpr bool IMG = STAGES == 6;      // window mode, whole reduction axis resident, weights through registers
     constexpr int WOFF = IMG ? 0 : 2 * BN; // LDS rows in front of the window (the two W tiles)
-    constexpr int NBUF = STAGES == 1 ? 1 : (STAGES == 4 ? 3 : 2);
+    constexpr int NBUF = STAGES == 1 ? 1 : ((STAGES == 4 || STAGES == 7) ? 3 : 2);
     constexpr int PITCH_E = DMA ? BK : PITCH;                              // LDS row pitch in elements
     constexpr int CP = BN + 16 / (int)sizeof(CT);                          // pitch of the staged C tile
     static_assert((STAGES >= 5 || BM * 8 % NT == 0) && BN * 8 % NT == 0, "loader mapping");
@@ -562,6 +562,41 @@ void igemm_kernel(IgemmArgs p) {
             cur = cur + 1 == 3 ? 0 : cur + 1;
         }
         __syncthreads();
+    } else if (STAGES == 7) {
+        // experiment (debug key 3 = 7): intra-workgroup ping-pong.  Three buffers; every K step has two phases
+        // separated by raw barriers: the lower half of the waves multiplies tile kt while the upper half issues its
+        // share of the DMA of tile kt+2, then the roles swap -- each SIMD's matrix pipe always has one wave whose
+        // program is MFMAs only, instead of every wave of the workgroup paying the DMA issue cycles at the same time.
+        constexpr int HALF = WGM * WGN / 2;
+        const bool lower = wid < HALF;
+        if (KT > 0) dma_tiles(0, 0);
+        if (KT > 1) dma_tiles(1, 1);
+        auto meet = [&](bool newest_in_flight) {
+#ifndef MTN_EMU
+            if (newest_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#else
+            __syncthreads();
+#endif
+        };
+        meet(KT > 1);
+        int cur = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            int nxt2 = cur + 2;
+            if (nxt2 >= 3) nxt2 -= 3;
+            const bool more = kt + 2 < KT;
+            if (lower) compute(cur);
+            else if (more) dma_tiles(kt + 2, nxt2);
+            // a wave's youngest batch is tile kt+2 (upper half, just issued) or tile kt+1 (lower half, issued one
+            // phase ago): leaving it in flight, everything older -- tile kt+1 for the upper half -- has landed
+            meet(lower ? kt + 1 < KT : more);
+            if (lower) { if (more) dma_tiles(kt + 2, nxt2); }
+            else compute(cur);
+            meet(lower ? more : kt + 1 < KT);
+            cur = cur + 1 == 3 ? 0 : cur + 1;
+        }
+        __syncthreads();
     } else if (DMA) {
         // tile kt+1 streams into the other buffer while tile kt is multiplied; the barrier's
         // vmcnt(0) is exactly the wait the next step needs (one tile in flight)
@@ -765,7 +800,7 @@ constexpr int IMG_BM = 144, IMG_BN = 256;
 // (Measured and dropped: 288 x 128 with waves 2 x 4 for the 24 x 24 stage-2 maps, +10 % slower than the 128 x 128
 //  double buffer; 256 x 64 with waves 4 x 2 for stage 1, +25 % slower than the 53 KB window mode -- DESIGN.md 7c.)
 static bool igemm_image_tile_ok(const IgemmArgs& p, int esz) {
-    if (!g_image_tiles || g_igemm_stages != 5 || esz != 2 || !igemm_window_shape(p) || p.N % IMG_BN) return false;
+    if (!g_image_tiles || (g_igemm_stages != 5 && g_igemm_stages != 7) || esz != 2 || !igemm_window_shape(p) || p.N % IMG_BN) return false;
     const int bk = ROW_BYTES / esz, cs = p.Cin / bk;
     if ((cs != 1 && cs != 2 && cs != 4) || p.Cin % bk) return false;
     if (igemm_window_bytes(p, IMG_BM, 0, cs) > 158 * 1024) return false;
@@ -776,14 +811,14 @@ static bool igemm_image_tile_ok(const IgemmArgs& p, int esz) {
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
 int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
-    constexpr size_t lds_ab = STAGES >= 3 ? (STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
+    constexpr size_t lds_ab = STAGES >= 3 ? (STAGES == 7 ? 3 : STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
     constexpr size_t csz = STAGES != 2 ? sizeof(T) : 4;
     constexpr size_t lds_c = (size_t)BM * (BN * csz + 16);
     constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
     constexpr size_t lds0 = lds_ab > lds_c ? lds_ab : lds_c;
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
     int win_cs = 0;
-    if (STAGES >= 5) {
+    if (STAGES == 5 || STAGES == 6) {
         win_cs = STAGES == 6 ? p.Cin / (ROW_BYTES / (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T));
         const size_t win = igemm_window_bytes(p, BM, STAGES == 6 ? 0 : BN, win_cs);
         const size_t rest = lds_c > lds_r ? lds_c : lds_r;
@@ -791,7 +826,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     }
 #ifndef MTN_EMU
     static MtnLdsAttr attr;
-    mtn_set_max_lds(attr, &igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>, STAGES >= 5 ? 160 * 1024 : lds);
+    mtn_set_max_lds(attr, &igemm_kernel<T, BM, BN, WGM, WGN, STAGES, MODE>, (STAGES == 5 || STAGES == 6) ? 160 * 1024 : lds);
 #endif
     const int tiles = mtn_cdiv(p.M, BM) * (p.N / BN);
     MTN_REQUIRE(!p.stats || p.stats_rows == mtn_cdiv(p.M, BM),
@@ -822,7 +857,7 @@ int launch_igemm_dma2(const IgemmArgs& p, hipStream_t stream) {
 
 template <class T, int BM, int BN, int WGM, int WGN>
 int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
-    if (g_igemm_stages == 5) {
+    if (g_igemm_stages == 5 || g_igemm_stages == 7) {
         if (igemm_window_ok(p, BM, BN, (int)sizeof(T))) return launch_igemm<T, BM, BN, WGM, WGN, 5, 2>(p, stream);
         return launch_igemm_dma2<T, BM, BN, WGM, WGN>(p, stream);
     }
@@ -845,7 +880,7 @@ static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 =
 static int igemm_config(int M, int N, int K) {
     (void)K;
     if (N % 128 == 0) {
-        if (g_igemm_tile == 1) return 0;
+        if (g_igemm_tile == 1 || g_igemm_tile >= 4) return 0;
         if (g_igemm_tile == 2) return 1;
         if (g_igemm_tile == 3) return 3;
         if (M < 128 * 64) return 1;
@@ -877,7 +912,16 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
             if (cfg == 3) return launch_igemm_dma2<T, 128, 64, 4, 1, 2>(p, stream);
         }
     }
-    if (cfg == 0 && g_igemm_stages == 5) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
+    if constexpr (sizeof(T) == 2) {
+        // experiments (debug key 6 = 5 / 6): 256x128 tile on 16 waves (4x4, 64x32 per wave), one workgroup per CU, with two
+        // and with three LDS buffers -- a quarter less L2->LDS traffic per flop than the 128x128 tile
+        if (cfg == 0 && g_igemm_stages == 5 && g_igemm_tile == 5) return launch_igemm_dma2<T, 256, 128, 4, 4>(p, stream);
+        if (cfg == 0 && g_igemm_stages == 5 && g_igemm_tile == 6) return launch_igemm_dma2<T, 256, 128, 4, 4, 4>(p, stream);
+        // experiment (debug key 3 = 7): ping-pong halves; debug key 6 = 4 picks the 256x128 tile for it
+        if (cfg == 0 && g_igemm_stages == 7)
+            return g_igemm_tile == 4 ? launch_igemm_dma2<T, 256, 128, 4, 2, 7>(p, stream) : launch_igemm_dma2<T, 128, 128, 4, 2, 7>(p, stream);
+    }
+    if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages == 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
     if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
     if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
@@ -886,7 +930,7 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
 }
 }  // namespace
 
-void mtn_igemm_set_stages(int n) { g_igemm_stages = (n >= 1 && n <= 5) ? n : 5; }
+void mtn_igemm_set_stages(int n) { g_igemm_stages = ((n >= 1 && n <= 5) || n == 7) ? n : 5; }
 void mtn_igemm_set_window_limit(int kb) { g_window_limit_kb = (kb > 0 && kb <= 150) ? kb : 53; }
 
 void mtn_igemm_set_image_tiles(int v) { g_image_tiles = v & 3; }
@@ -914,6 +958,8 @@ int mtn_igemm_tiles_m(int M, int N, int K) {
 int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_tiles_m(p);
     if (igemm_image_tile_ok(p, dtype == MTN_BF16 ? 2 : 4)) return mtn_cdiv(p.M, IMG_BM);
+    if (dtype == MTN_BF16 && ((g_igemm_stages == 7 && g_igemm_tile == 4) || (g_igemm_stages == 5 && g_igemm_tile >= 5)) && igemm_config(p.M, p.N, p.K) == 0)
+        return mtn_cdiv(p.M, 256);
     return mtn_igemm_tiles_m(p.M, p.N, p.K);
 }
 
@@ -930,7 +976,7 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     }
     const int bk = dtype == MTN_BF16 ? 64 : 32;
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "igemm: bad dtype %d", dtype);
-    MTN_REQUIRE(p.act != MTN_ACT_GELU_GRAD_ || (igemm_pointwise(p) && g_igemm_stages == 5 && p.aux_out),
+    MTN_REQUIRE(p.act != MTN_ACT_GELU_GRAD_ || (igemm_pointwise(p) && (g_igemm_stages == 5 || g_igemm_stages == 7) && p.aux_out),
                 "igemm: the GELU-backward epilogue exists for 1x1 taps in the default pipeline only");
     MTN_REQUIRE(p.M > 0 && p.N > 0 && p.N % 64 == 0, "igemm: N=%d must be a positive multiple of 64 (M=%d)", p.N, p.M);
     MTN_REQUIRE(p.Cin % bk == 0, "igemm: Cin=%d must be a multiple of %d", p.Cin, bk);

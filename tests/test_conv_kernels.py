@@ -517,3 +517,32 @@ def test_pack_weights_layouts(be, dtype):
             wf = w * scale[so:so + w.shape[0]].view(-1, 1, 1, 1) if (so >= 0 and mode == 0) else w
             want = want_of(wf, mode, desc[2 * j + mode][5] >= 2)
             assert torch.equal(dst2[o:o + w.numel()].cpu().view(torch.int32), want.view(torch.int32)), (j, mode, "folded")
+
+
+@pytest.mark.parametrize("stages,tile", [(7, 1), (7, 4), (5, 5), (5, 6)])
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 192, 128, 1, 1), (2, 64, 64, 64, 128, 3, 1), (2, 64, 64, 64, 256, 1, 1)])
+def test_conv_fwd_pipeline_experiments(be, cfg, stages, tile):
+    """the K-loop experiments kept behind debug keys stay correct: key 3 = 7, the ping-pong loop (half the waves
+    multiply while the other half issues the DMA of the tile two steps ahead) on 128x128 and 256x128 (key 6 = 4)
+    tiles; key 6 = 5 / 6, the 16-wave 256x128 tile with two / three buffers.  K loops of 1, 3 and 9 steps, with statistics"""
+    from hand_gesture_recognition_amd import lib
+    dtype = torch.bfloat16
+    B, H, W, Cin, Cout, k, s = cfg
+    x = _rand((B, H, W, Cin), dtype, 41)
+    w = _rand((Cout, Cin, k, k), torch.float32, 42) / (Cin * k * k) ** 0.5
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dtype).float(), None, s, k // 2).permute(0, 2, 3, 1)
+    M = B * H * W
+    lib.call("mtn_debug_set", 3, stages)
+    lib.call("mtn_debug_set", 6, tile)
+    try:
+        y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=be.device)
+        stats = torch.full((ops.conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, k, s), 2, Cout), float("nan"), device=be.device)
+        ops.conv_fwd(x.to(be.device), pack_krsc(w, dtype).to(be.device), y, stats, k, s)
+        be.sync()
+    finally:
+        lib.call("mtn_debug_set", 3, 5)
+        lib.call("mtn_debug_set", 6, 0)
+    assert stats.shape[0] == (M + (255 if tile >= 4 else 127)) // (256 if tile >= 4 else 128)
+    assert rel_err(y.float(), ref) < tol(dtype)
+    yf = y.float().cpu().reshape(M, Cout)
+    assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3
