@@ -12,6 +12,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` (pytest.ini): worker processes only for the CPU suite, i.e. when the marker expression excludes
+    the gpu tests; any run that may touch the card stays in ONE process."""
+    expr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    if "notgpu" not in expr:
+        return 0
+    return max(1, min(6, (os.cpu_count() or 2) - 2))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "x3: fp32 tensors multiplied in split-bf16 mode (MTN_DTYPE_F32X3)")

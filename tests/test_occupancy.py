@@ -28,7 +28,7 @@ BUDGETS = [
     ("igemm_kernel<bf16_t, 128, 64, 4, 1, 3,", 168, "4 waves x 3 workgroups per CU"),
     ("igemm_kernel<bf16_t, 128, 64, 4, 1, 5, 2>", 168, "window mode: 3 workgroups per CU (53 KB of LDS each)"),
     ("dgrad2_kernel<bf16_t>", 128, "8 waves x 2 workgroups per CU"),
-    ("wgrad_dma2_kernel<bf16_t, 128, 128, 4, 2>", 128, "8 waves x 2 workgroups per CU"),
+    ("wgrad_dma2_kernel<bf16_t, 128, 128, 4, 2, false>", 128, "8 waves x 2 workgroups per CU"),
     ("wgrad3_kernel<bf16_t>", 256, "8 waves, one workgroup per CU"),
     ("wgrad_row3_kernel<bf16_t>", 256, "4 waves x 2 workgroups per CU (80 KB of LDS each)"),
     ("igemm_kernel<bf16_t, 144, 256, 1, 8, 6, 2>", 256, "image tiles: 8 waves, one workgroup per CU"),
