@@ -260,14 +260,15 @@ size_t dgrad2_lds(const IgemmArgs& p, int esz) {
     return loop > epi ? loop : epi;
 }
 
-int g_dgrad2 = 1;     // debug key 15
+int g_dgrad2 = 1;     // debug key 15 (0: off, 1: on, n >= 2: on with an LDS limit of n KB)
+int g_dgrad2_lds_kb = 96;    // two workgroups per CU up to 80 KB; the 96-column maps of 384x384 images (92 KB, one per CU) still beat the generic parity-major igemm (config 4: -0.12 ms)
 
 template <class T>
 int launch_dgrad2(const IgemmArgs& p, hipStream_t stream) {
     const size_t lds = dgrad2_lds(p, (int)sizeof(T));
 #ifndef MTN_EMU
     static MtnLdsAttr attr;
-    mtn_set_max_lds(attr, &dgrad2_kernel<T>, 80 * 1024);
+    mtn_set_max_lds(attr, &dgrad2_kernel<T>, 160 * 1024);
 #endif
     const int tiles_m = mtn_cdiv((long)p.B * p.H * p.W, D2_BM);
     MTN_REQUIRE(!p.stats || p.stats_rows == tiles_m, "dgrad2: the statistics slab was sized for %d row tiles, this launch writes %d",
@@ -279,14 +280,17 @@ int launch_dgrad2(const IgemmArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-void mtn_dgrad2_set(int on) { g_dgrad2 = on ? 1 : 0; }
+void mtn_dgrad2_set(int on) {
+    g_dgrad2 = on ? 1 : 0;
+    g_dgrad2_lds_kb = on >= 2 && on <= 160 ? on : 96;
+}
 
 // the fused form serves 3x3 stride-2 pad-1 data gradients whose window still lets two workgroups share a CU
 bool mtn_dgrad2_ok(const IgemmArgs& p, int dtype) {
     const int esz = dtype == MTN_BF16 ? 2 : 4, bk = 128 / esz;
     return g_dgrad2 && p.pm && p.KH == 3 && p.KW == 3 && p.div == 2 && p.mul == 1 && p.sgn == -1 && p.off == 1 &&
            p.OH == 2 * p.H && p.OW == 2 * p.W && p.Cin % (D2_CS * bk) == 0 && p.N % D2_BN == 0 && !p.bias && (!p.stats || p.bn_y) &&
-           p.act == MTN_ACT_NONE && !p.aux_out && dgrad2_lds(p, esz) <= 80 * 1024;
+           p.act == MTN_ACT_NONE && !p.aux_out && dgrad2_lds(p, esz) <= (size_t)g_dgrad2_lds_kb * 1024;
 }
 
 int mtn_dgrad2_tiles_m(const IgemmArgs& p) { return mtn_cdiv((long)p.B * p.H * p.W, D2_BM); }

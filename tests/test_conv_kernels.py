@@ -222,6 +222,7 @@ def test_conv_dgrad(be, stages, dtype, cfg):
     (3, 12, 20, 128, 256),       # two row tiles (180 dy pixels), two column tiles, two channel slabs (bf16) / four (fp32)
     (2, 2, 2, 64, 128),          # 1 x 1 dy: every neighbour is padding
     (5, 16, 16, 64, 128),        # rows cross image borders inside a tile
+    (1, 8, 192, 64, 128),        # 96-column dy (384x384 images): 92 KB window, one workgroup per CU
 ])
 def test_conv_dgrad_stride2_fused(be, dtype, with_res, cfg):
     """dgrad2.hip (all four output parities per workgroup) against autograd, writing into a channel
