@@ -301,9 +301,11 @@ void igemm_kernel(IgemmArgs p) {
             const unsigned e = (unsigned)((a_base[i] + iy * p.W + ix) * p.lda + cc) * (unsigned)sizeof(T);
             buf_glds16(bufA, (((a_vy[i] >> kh) & (a_vx[i] >> kw)) & 1u) ? e : 0xFFFFFFF0u, a + (wid * RA + i) * 1024);
         }
-        MTN_UNROLL for (int i = 0; i < RB; ++i)
-            buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
-                       b + (wid * RB + i) * 1024);
+        if constexpr (STAGES != 8) {
+            MTN_UNROLL for (int i = 0; i < RB; ++i)
+                buf_glds16(bufW, (unsigned)((n0 + brow0 + i * rstep_b) * p.K + k0 + chunk * VEC) * (unsigned)sizeof(T),
+                           b + (wid * RB + i) * 1024);
+        }
     };
     constexpr bool X3 = std::is_same<T, f32x3_t>::value;
     auto store_tiles = [&](int stage) {
@@ -562,6 +564,37 @@ void igemm_kernel(IgemmArgs p) {
             cur = cur + 1 == 3 ? 0 : cur + 1;
         }
         __syncthreads();
+    } else if (STAGES == 8) {
+        // experiment (debug key 3 = 8): only the A tile goes through LDS (DMA double buffer); a wave's weight fragments
+        // come straight from global memory into registers one K step ahead, as in the image-tile kernel -- half the
+        // LDS-DMA bytes per step (the per-CU DMA intake is what the K-heavy layers track).  Taps in
+        // natural order only (MODE 1, 2, 4): K step kt starts at weight column kt * BK.
+        constexpr int KS = BK / KI;
+        typename Mma<T>::Frag wq0[KS][FN], wq1[KS][FN];
+        const T* wbase = gW + (long)(n0 + wn * WN + frow) * p.K + fk;
+        auto load_w = [&](int kt, typename Mma<T>::Frag (&wq)[KS][FN]) {
+            const T* w = wbase + kt * BK;
+            MTN_UNROLL for (int ks = 0; ks < KS; ++ks)
+                MTN_UNROLL for (int j = 0; j < FN; ++j) wq[ks][j] = Mma<T>::load(w + (long)j * 16 * p.K + ks * KI);
+        };
+        auto compute_w = [&](int stage, typename Mma<T>::Frag (&wq)[KS][FN]) {
+            const T* a = sA + stage * BM * BK + (wm * WM + frow) * BK;
+            const int sw = frow & 7;
+            mma_step([&](int ks, int i) { return RowFrag<T>::load(a + i * 16 * BK, ks, fg, sw); },
+                     [&](int ks, int j) { return wq[ks][j]; });
+        };
+        if (KT > 0) { dma_tiles(0, 0); load_w(0, wq0); }
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 1 < KT) { dma_tiles(kt + 1, 1); load_w(kt + 1, wq1); }
+            compute_w(0, wq0);
+            __syncthreads();
+            if (kt + 1 < KT) {
+                if (kt + 2 < KT) { dma_tiles(kt + 2, 0); load_w(kt + 2, wq0); }
+                compute_w(1, wq1);
+                __syncthreads();
+            }
+        }
     } else if (STAGES == 7) {
         // experiment (debug key 3 = 7): intra-workgroup ping-pong.  Three buffers; every K step has two phases
         // separated by raw barriers: the lower half of the waves multiplies tile kt while the upper half issues its
@@ -800,7 +833,7 @@ constexpr int IMG_BM = 144, IMG_BN = 256;
 // (Measured and dropped: 288 x 128 with waves 2 x 4 for the 24 x 24 stage-2 maps, +10 % slower than the 128 x 128
 //  double buffer; 256 x 64 with waves 4 x 2 for stage 1, +25 % slower than the 53 KB window mode -- DESIGN.md 7c.)
 static bool igemm_image_tile_ok(const IgemmArgs& p, int esz) {
-    if (!g_image_tiles || (g_igemm_stages != 5 && g_igemm_stages != 7) || esz != 2 || !igemm_window_shape(p) || p.N % IMG_BN) return false;
+    if (!g_image_tiles || (g_igemm_stages != 5 && g_igemm_stages < 7) || esz != 2 || !igemm_window_shape(p) || p.N % IMG_BN) return false;
     const int bk = ROW_BYTES / esz, cs = p.Cin / bk;
     if ((cs != 1 && cs != 2 && cs != 4) || p.Cin % bk) return false;
     if (igemm_window_bytes(p, IMG_BM, 0, cs) > 158 * 1024) return false;
@@ -811,7 +844,7 @@ static bool igemm_image_tile_ok(const IgemmArgs& p, int esz) {
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
 int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
-    constexpr size_t lds_ab = STAGES >= 3 ? (STAGES == 7 ? 3 : STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
+    constexpr size_t lds_ab = STAGES == 8 ? 2 * (size_t)BM * ROW_BYTES : STAGES >= 3 ? (STAGES == 7 ? 3 : STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
     constexpr size_t csz = STAGES != 2 ? sizeof(T) : 4;
     constexpr size_t lds_c = (size_t)BM * (BN * csz + 16);
     constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
@@ -857,7 +890,7 @@ int launch_igemm_dma2(const IgemmArgs& p, hipStream_t stream) {
 
 template <class T, int BM, int BN, int WGM, int WGN>
 int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
-    if (g_igemm_stages == 5 || g_igemm_stages == 7) {
+    if (g_igemm_stages == 5 || g_igemm_stages >= 7) {
         if (igemm_window_ok(p, BM, BN, (int)sizeof(T))) return launch_igemm<T, BM, BN, WGM, WGN, 5, 2>(p, stream);
         return launch_igemm_dma2<T, BM, BN, WGM, WGN>(p, stream);
     }
@@ -917,11 +950,17 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
         // and with three LDS buffers -- a quarter less L2->LDS traffic per flop than the 128x128 tile
         if (cfg == 0 && g_igemm_stages == 5 && g_igemm_tile == 5) return launch_igemm_dma2<T, 256, 128, 4, 4>(p, stream);
         if (cfg == 0 && g_igemm_stages == 5 && g_igemm_tile == 6) return launch_igemm_dma2<T, 256, 128, 4, 4, 4>(p, stream);
+        // experiment (debug key 3 = 8): weights through registers, 2x4 waves (64x32 per wave)
+        if (cfg == 0 && g_igemm_stages == 8 && !p.pm && (igemm_pointwise(p) || (p.KH == 3 && p.KW == 3))) {
+            if (igemm_pointwise(p) && p.act == MTN_ACT_GELU_GRAD_) return launch_igemm<T, 128, 128, 2, 4, 8, 4>(p, stream);
+            if (igemm_pointwise(p)) return launch_igemm<T, 128, 128, 2, 4, 8, 1>(p, stream);
+            return launch_igemm<T, 128, 128, 2, 4, 8, 2>(p, stream);
+        }
         // experiment (debug key 3 = 7): ping-pong halves; debug key 6 = 4 picks the 256x128 tile for it
         if (cfg == 0 && g_igemm_stages == 7)
             return g_igemm_tile == 4 ? launch_igemm_dma2<T, 256, 128, 4, 2, 7>(p, stream) : launch_igemm_dma2<T, 128, 128, 4, 2, 7>(p, stream);
     }
-    if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages == 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
+    if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages >= 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
     if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
     if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
@@ -930,7 +969,7 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
 }
 }  // namespace
 
-void mtn_igemm_set_stages(int n) { g_igemm_stages = ((n >= 1 && n <= 5) || n == 7) ? n : 5; }
+void mtn_igemm_set_stages(int n) { g_igemm_stages = ((n >= 1 && n <= 5) || n == 7 || n == 8) ? n : 5; }
 void mtn_igemm_set_window_limit(int kb) { g_window_limit_kb = (kb > 0 && kb <= 150) ? kb : 53; }
 
 void mtn_igemm_set_image_tiles(int v) { g_image_tiles = v & 3; }
@@ -976,7 +1015,7 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     }
     const int bk = dtype == MTN_BF16 ? 64 : 32;
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "igemm: bad dtype %d", dtype);
-    MTN_REQUIRE(p.act != MTN_ACT_GELU_GRAD_ || (igemm_pointwise(p) && (g_igemm_stages == 5 || g_igemm_stages == 7) && p.aux_out),
+    MTN_REQUIRE(p.act != MTN_ACT_GELU_GRAD_ || (igemm_pointwise(p) && (g_igemm_stages == 5 || g_igemm_stages >= 7) && p.aux_out),
                 "igemm: the GELU-backward epilogue exists for 1x1 taps in the default pipeline only");
     MTN_REQUIRE(p.M > 0 && p.N > 0 && p.N % 64 == 0, "igemm: N=%d must be a positive multiple of 64 (M=%d)", p.N, p.M);
     MTN_REQUIRE(p.Cin % bk == 0, "igemm: Cin=%d must be a multiple of %d", p.Cin, bk);

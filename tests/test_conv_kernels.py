@@ -520,12 +520,13 @@ def test_pack_weights_layouts(be, dtype):
             assert torch.equal(dst2[o:o + w.numel()].cpu().view(torch.int32), want.view(torch.int32)), (j, mode, "folded")
 
 
-@pytest.mark.parametrize("stages,tile", [(7, 1), (7, 4), (5, 5), (5, 6)])
+@pytest.mark.parametrize("stages,tile", [(7, 1), (7, 4), (5, 5), (5, 6), (8, 1)])
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 192, 128, 1, 1), (2, 64, 64, 64, 128, 3, 1), (2, 64, 64, 64, 256, 1, 1)])
 def test_conv_fwd_pipeline_experiments(be, cfg, stages, tile):
     """the K-loop experiments kept behind debug keys stay correct: key 3 = 7, the ping-pong loop (half the waves
     multiply while the other half issues the DMA of the tile two steps ahead) on 128x128 and 256x128 (key 6 = 4)
-    tiles; key 6 = 5 / 6, the 16-wave 256x128 tile with two / three buffers.  K loops of 1, 3 and 9 steps, with statistics"""
+    tiles; key 6 = 5 / 6, the 16-wave 256x128 tile with two / three buffers; key 3 = 8, weight fragments from global memory
+    into registers.  K loops of 1, 3 and 9 steps, with statistics"""
     from hand_gesture_recognition_amd import lib
     dtype = torch.bfloat16
     B, H, W, Cin, Cout, k, s = cfg
