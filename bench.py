@@ -42,8 +42,8 @@ BACKBONE_MB_PER_IMG = 3 * 15.3     # conv part of the on
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--size", type=int, default=192)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"],
