@@ -172,3 +172,31 @@ def test_overlapped_allreduce_two_ranks_on_the_gpu():
             assert torch.equal(ga, gb)
     assert torch.equal(r0[True][0], r1[True][0]), "replicas diverged"
     assert not torch.equal(r0[True][2], r1[True][2]), "ranks must have seen different shards"
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_code_path_rehearsal():
+    """bench.py's N > 1 path (rank-dependent shards, barrier + max-over-ranks timing, per-rank / exposed-communication
+    figures, the instrumented roofline step on every rank) launched exactly as the driver launches it, with gloo
+    standing in for RCCL because this box has one GPU (MTN_BENCH_BACKEND, bench.py)."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MTN_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+                        "--warmup", "2", "--windows", "1"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    rk = out["ranks"]
+    assert rk["backend"] == "gloo" and len(rk["ms_per_step_per_rank"]) == 2 and rk["buckets"] == 5
+    assert rk["gradient_bytes_all_reduced"] == 7409000 * 4 and rk["comm_exposed_ms"] >= 0
+    assert out["roofline"]["launches_per_step"] == 69
