@@ -424,6 +424,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 18) { mtn_wgrad_set_row3(value); return MTN_OK; }
     if (key == 19) { mtn_igemm_set_x3_waves(value); return MTN_OK; }
     if (key == 20) { mtn_wgrad_set_x3_sep(value); return MTN_OK; }
+    if (key == 21) { mtn_conv1_set_x3(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

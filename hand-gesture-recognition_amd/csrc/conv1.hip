@@ -314,7 +314,7 @@ constexpr int ONE_K = KK;                     // patch slot that carries the con
 // a lane's quad is 4 consecutive channels of one pixel, so it needs only 4 x 4 BatchNorm constants),
 // forms dz, keeps sum dz*xhat in 4 registers and writes dz to LDS for the pixel contraction.
 template <class T, bool TR, bool SILU>
-__global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
                                                         const T* __restrict__ dout, const float* __restrict__ ss,
                                                         const float* __restrict__ mr, float* __restrict__ partial, int B,
                                                         int H, int W, int OH, int OW, int px_per_block) {
@@ -554,6 +554,8 @@ int mtn_conv1_bn_act_run(const float* x, const void* w, const float* scale_shift
     return conv1_fused_launch<2>(x, w, out, nullptr, scale_shift, act, dtype, B, H, W, stream);
 }
 
+static int g_conv1_x3 = 0;
+void mtn_conv1_set_x3(int v) { g_conv1_x3 = v ? 1 : 0; }
 static int kBwdPx = 3072;           // pixels per workgroup of the fused backward (debug key 12): 768 workgroups = one round at B = 256
 void mtn_conv1_set_bwd_px(int n) { kBwdPx = n >= 64 ? (n / 64) * 64 : 3072; }
 int mtn_conv1_bwd_blocks(long M) { return (int)((M + kBwdPx - 1) / kBwdPx); }
@@ -574,6 +576,8 @@ int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const flo
                mean_rstd, partial, B, H, W, OH, OW, kBwdPx)
     if (dtype == MTN_BF16) {
         if (act == MTN_ACT_SILU) MTN_CONV1_BWD(bf16_t, true, true); else MTN_CONV1_BWD(bf16_t, true, false);
+    } else if (g_conv1_x3) {      // experiment (debug key 21): the fp32 stem backward on split-bf16 products
+        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(f32x3_t, false, true); else MTN_CONV1_BWD(f32x3_t, false, false);
     } else {
         if (act == MTN_ACT_SILU) MTN_CONV1_BWD(float, false, true); else MTN_CONV1_BWD(float, false, false);
     }

@@ -437,6 +437,18 @@ def test_conv1_fused_stem(be, dtype, cfg):
         lib.call("mtn_debug_set", 11, 0)
 
 
+@pytest.mark.parametrize("cfg", [(2, 16, 16), (3, 32, 32)])
+def test_conv1_backward_on_split_bf16_products(be, cfg):
+    """debug key 21: the fp32 stem backward with its two products (recomputed conv, pixel contraction) as split-bf16
+    MFMAs -- same gates as the exact-f32 form"""
+    from hand_gesture_recognition_amd import lib
+    lib.call("mtn_debug_set", 21, 1)
+    try:
+        _conv1_fused_case(be, torch.float32, *cfg)
+    finally:
+        lib.call("mtn_debug_set", 21, 0)
+
+
 def _conv1_fused_case(be, dtype, B, H, W):
     d = be.device
     x = _rand((B, 3, H, W), torch.float32, 51)
