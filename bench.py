@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0:
                         the measured errors of all three modes against the CPU oracle at BASELINE config 1 (B=4);
   configs               BASELINE configs 4 (384x384, B=128: attention stress) and 5 (GELAN only, B=512: conv HBM
                         stress): images/sec + the roofline figure of the kernel family each one stresses;
+  inference             eval() forward with BatchNorm folded (SURVEY 8f row 3): images/sec at B=256, latency at B=1;
   cpu_baseline          the oracle (CPU port of the reference path) on the host cores;
   ranks (N > 1)         rccl_ranks, per-rank ms/step, comm_exposed_ms (time the compute stream waited for RCCL).
 """
@@ -34,6 +35,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (same guide: ~6.3 TB/s achievable)
 TRAIN_GFLOP_PER_IMG = 13.09        # fwd + dgrad + wgrad @192^2
+FWD_GFLOP_PER_IMG = 4.374           # forward @192^2
 TRAIN_GFLOP_PER_IMG_384 = 55.4
 BACKBONE_GFLOP_PER_IMG = 11.27
 BACKBONE_MB_PER_IMG = 3 * 15.3     # conv part of the one-read-one-write byte model, x3 for the train step
@@ -247,6 +249,30 @@ def config4(dev, steps=10, warmup=3):
                          "attention_bwd_us": round(tb * 1e6, 1), "attention_bwd_tflops": round(bfl / tb / 1e12, 1)}}
 
 
+def inference(dev):
+    """SURVEY 8f row 3 / export.py:41-45: the module in eval() (BatchNorm folded into the packed weights, one launch per
+    Conv unit), forward only, 192x192: images/sec at B=256 and latency at B=1 (the detector's frame-at-a-time use)."""
+    from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+    out = {"workload": "MultiTaskNet 192x192 eval() forward (BN folded), logits + heat-maps + attention map"}
+    for name, dt in (("bf16", torch.bfloat16), ("bf16x3", "bf16x3")):
+        torch.manual_seed(42)
+        model = MultiTaskNet(21, 19, [192, 192], compute_dtype=dt).to(dev).eval()
+        r = {}
+        with torch.no_grad():
+            for B, steps in ((256, 20), (1, 100)):
+                x = torch.randn(B, 3, 192, 192, device=dev)
+                t = _timed(lambda: model(x), steps, 3)
+                if B == 1:
+                    r["latency_ms_b1"] = round(t * 1e3, 3)
+                else:
+                    r["images_per_sec_b256"] = round(B / t, 1)
+                    r["algorithmic_tflops_b256"] = round(B / t * FWD_GFLOP_PER_IMG / 1e3, 1)
+        out[name] = r
+        del model
+        torch.cuda.empty_cache()
+    return out
+
+
 def config5(dev, steps=10, warmup=3):
     """BASELINE config 5: GELAN backbone only, 192x192, B=512, bf16 forward + backward with a synthetic upstream
     gradient (conv HBM stress): roofline = algorithmic bytes of the conv stack / step time."""
@@ -418,6 +444,7 @@ def main():
             out["validation"] = validation(a, dev, ref)
         if not a.no_configs and a.dtype == "bf16":
             out["configs"] = {"4": config4(dev), "5": config5(dev)}
+            out["inference"] = inference(dev)
         if base is not None:
             out["cpu_baseline"] = base
     if rank == 0:
