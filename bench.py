@@ -252,6 +252,7 @@ def config4(dev, steps=10, warmup=3):
 def inference(dev):
     """SURVEY 8f row 3 / export.py:41-45: the module in eval() (BatchNorm folded into the packed weights, one launch per
     Conv unit), forward only, 192x192: images/sec at B=256 and latency at B=1 (the detector's frame-at-a-time use)."""
+    from hand_gesture_recognition_amd.infer import InferenceSession
     from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
     out = {"workload": "MultiTaskNet 192x192 eval() forward (BN folded), logits + heat-maps + attention map"}
     for name, dt in (("bf16", torch.bfloat16), ("bf16x3", "bf16x3")):
@@ -264,6 +265,9 @@ def inference(dev):
                 t = _timed(lambda: model(x), steps, 3)
                 if B == 1:
                     r["latency_ms_b1"] = round(t * 1e3, 3)
+                    sess = InferenceSession(model, 1, use_graph=True)     # BN folded once + one hipGraph replay per frame
+                    r["latency_ms_b1_session_graph"] = round(_timed(lambda: sess(x), 200, 5) * 1e3, 3)
+                    del sess
                 else:
                     r["images_per_sec_b256"] = round(B / t, 1)
                     r["algorithmic_tflops_b256"] = round(B / t * FWD_GFLOP_PER_IMG / 1e3, 1)

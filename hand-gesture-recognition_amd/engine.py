@@ -386,12 +386,13 @@ class Engine:
         return cur
 
     @_in_plan_mode
-    def forward(self, x, training=True, want_attn=True):
-        """MultiTaskNet.forward (model/multitasknet.py:24-29) -> (logits, heatmaps, attnmap)."""
+    def forward(self, x, training=True, want_attn=True, refold=True):
+        """MultiTaskNet.forward (model/multitasknet.py:24-29) -> (logits, heatmaps, attnmap).  ``refold=False``
+        (eval only): the folded weights of the previous eval forward are still current (infer.InferenceSession)."""
         assert tuple(x.shape) == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
         if training:
             self.pack_weights()
-        else:
+        elif refold:
             self.fold_batchnorm()
         feats = self.backbone_forward(x, training)
         up = self.u_proj
