@@ -12,13 +12,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hand-gesture-recognition_amd", "csrc")
-EMU_LIB = os.path.join(ROOT, "hand-gesture-recognition_amd", "libmtn_emu.so")
+# MTN_EMU_LIB: another build of the CPU executor library, e.g. one compiled with -fsanitize=address,undefined
+# (tools/asan_emu.sh); it is used as it is, not rebuilt
+EMU_LIB = os.environ.get("MTN_EMU_LIB") or os.path.join(ROOT, "hand-gesture-recognition_amd", "libmtn_emu.so")
 
 _built = {}
 
 
 def _ensure_emu():
-    if "emu" not in _built:
+    if "emu" not in _built and not os.environ.get("MTN_EMU_LIB"):
         subprocess.run(["make", "-C", CSRC, "-j4", "emu"], check=True, stdout=subprocess.DEVNULL)
         _built["emu"] = True
 

@@ -13,6 +13,10 @@
 // MFMA lane maps follow /opt/skills/guides/cdna_hip_programming.md section 3; they are
 // re-validated against the hardware by tests/test_mfma_layout.py (-m gpu).
 #pragma once
+#if defined(__SANITIZE_ADDRESS__)
+#define MTN_EMU_ASAN 1
+#include <sanitizer/asan_interface.h>
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -152,8 +156,16 @@ inline void launch(dim3 grid, dim3 block, size_t smem, F body) {
     for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
         blockIdx = dim3(bx, by, bz);
+#ifdef MTN_EMU_ASAN
+        __asan_unpoison_memory_region(dyn.data(), dyn.size());
+#endif
         std::memset(dyn.data(), 0xFF, dyn.size());   // LDS is uninitialised: poison with NaNs
         g_dyn_smem = (char*)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
+#ifdef MTN_EMU_ASAN
+        // sanitizer build (tools/asan_emu.sh): the alignment slack behind the requested bytes is poisoned, so an LDS
+        // access one byte past the launch's dynamic shared memory is reported like any other heap overflow
+        __asan_poison_memory_region(g_dyn_smem + smem, (size_t)(dyn.data() + dyn.size() - (g_dyn_smem + smem)));
+#endif
         g_alive = n;
         g_bar_count = 0;
         for (int w = 0; w < nw; ++w) {
@@ -192,6 +204,9 @@ inline void launch(dim3 grid, dim3 block, size_t smem, F body) {
             }
         }
     }
+#ifdef MTN_EMU_ASAN
+    __asan_unpoison_memory_region(dyn.data(), dyn.size());
+#endif
 }
 
 // ---- shuffles ---------------------------------------------------------------------------
