@@ -32,7 +32,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(7)
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dt = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[a.dtype]
     model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=dt).to(dev)
     step = TrainStep(model, a.batch, lr=1e-3)
     batch = synthetic_batch(a.batch, (a.size, a.size), 21, 19, dev, 99)
