@@ -910,8 +910,9 @@ static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 =
 // model (short-K ones included: +9..17 %) except where its last round of workgroups is nearly
 // empty -- 576..580 tiles on 512 slots (stage-3 3x3, proj, the 256-wide Linears): there the smaller
 // tile is 5..10 % faster (per-layer table in DESIGN.md section 7b).
+// (K >= 2048 -- the stage-3 3x3 layers where the image tile does not apply, i.e. the fp32-storage modes: the larger tile
+// still wins at 0.56 of a round, 176 -> 161 us in the split-bf16 mode; at K = 512 (proj) it does not)
 static int igemm_config(int M, int N, int K) {
-    (void)K;
     if (N % 128 == 0) {
         if (g_igemm_tile == 1 || g_igemm_tile >= 4) return 0;
         if (g_igemm_tile == 2) return 1;
@@ -919,7 +920,7 @@ static int igemm_config(int M, int N, int K) {
         if (M < 128 * 64) return 1;
         const double x128 = (double)mtn_cdiv(M, 128) * (N / 128) / 512.0;
         const double e128 = x128 / (double)(long)(x128 + 0.999999);
-        return e128 < 0.6 ? 1 : 0;
+        return e128 < (K >= 2048 ? 0.5 : 0.6) ? 1 : 0;
     }
     if (g_tile_n64 == 256 && M >= 256 * 256) return 2;
     return 3;

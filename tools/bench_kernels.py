@@ -46,6 +46,9 @@ def main():
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from hand_gesture_recognition_amd import lib as _lib
+    if a.dtype == "bf16x3":          # fp32 tensors, split-bf16 products (weights: any bits do for timing)
+        from hand_gesture_recognition_amd import ops as _ops
+        _ops.set_f32_matmul(_ops.F32X3)
     if a.lib:
         _lib.use_library(os.path.abspath(a.lib))
     _lib.call("mtn_debug_set", 3, a.stages)
