@@ -805,7 +805,13 @@ static size_t igemm_window_bytes(const IgemmArgs& p, int bm, int bn, int cs) {  
     const size_t wr8 = (size_t)((bm + 2 * (p.W + 1) + 7) & ~7);
     return (2 * (size_t)bn + cs * wr8 + 1) * ROW_BYTES;
 }
-static int igemm_window_cs(const IgemmArgs& p, int esz) { return p.Cin / (ROW_BYTES / esz) >= 2 ? 2 : 1; }
+static int g_window_limit_kb = 53;
+// resident channel slabs of the window: two where they fit the LDS limit, else one (fp32 storage, 64-channel layers of
+// stage 1: two 32-channel slabs are 59 KB of window, one is 30 KB and keeps three workgroups per CU)
+static int igemm_window_cs(const IgemmArgs& p, int esz, int bm, int bn) {
+    if (p.Cin / (ROW_BYTES / esz) < 2) return 1;
+    return igemm_window_bytes(p, bm, bn, 2) <= (size_t)g_window_limit_kb * 1024 ? 2 : 1;
+}
 static bool igemm_window_shape(const IgemmArgs& p) {
     return p.KH == 3 && p.KW == 3 && p.mul == 1 && p.div == 1 && !p.pm && p.OH == p.H && p.OW == p.W;
 }
@@ -816,10 +822,9 @@ static bool igemm_window_shape(const IgemmArgs& p) {
 // Debug key 9 raises the limit (tests run every shape through the window path).
 static int g_tile_n64 = 128;     // rows per tile for 64-wide outputs (debug key 4)
 static int g_igemm_stages = 5;   // window mode where it pays, LDS-DMA double buffer elsewhere
-static int g_window_limit_kb = 53;
 static bool igemm_window_ok(const IgemmArgs& p, int bm, int bn, int esz) {
     const int bk = ROW_BYTES / esz;
-    const int cs = igemm_window_cs(p, esz);
+    const int cs = igemm_window_cs(p, esz, bm, bn);
     return igemm_window_shape(p) && p.Cin % (cs * bk) == 0 && igemm_window_bytes(p, bm, bn, cs) <= (size_t)g_window_limit_kb * 1024;
 }
 
@@ -852,7 +857,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
     int win_cs = 0;
     if (STAGES == 5 || STAGES == 6) {
-        win_cs = STAGES == 6 ? p.Cin / (ROW_BYTES / (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T));
+        win_cs = STAGES == 6 ? p.Cin / (ROW_BYTES / (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T), BM, BN);
         const size_t win = igemm_window_bytes(p, BM, STAGES == 6 ? 0 : BN, win_cs);
         const size_t rest = lds_c > lds_r ? lds_c : lds_r;
         lds = win > rest ? win : rest;
