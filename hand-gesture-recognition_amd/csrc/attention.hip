@@ -256,8 +256,17 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
             MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
                 if (FULL || kt < nkt) {
                     float* ap = attn + ((long)bh * N + q) * N + kt * 16 + 4 * g;
-                    MTN_UNROLL for (int r = 0; r < 4; ++r)
-                        if (kt * 16 + 4 * g + r < N) ap[r] = s[kt][r] * inv;
+                    if (FULL ? (kt < MAXT - 2) : (kt * 16 + 16 <= N)) {
+                        // a whole key tile: ONE 16-byte store per lane (rows of N floats are only 4-byte aligned) --
+                        // 64-byte runs per query row instead of four scattered dword stores per lane
+                        f32x4u_t v;
+                        MTN_UNROLL for (int r = 0; r < 4; ++r) v[r] = s[kt][r] * inv;
+                        *reinterpret_cast<f32x4u_t*>(ap) = v;
+                        MTN_SCHED_FENCE();             // (one tile's four products at a time: batched, 38 tiles of them spill)
+                    } else {
+                        MTN_UNROLL for (int r = 0; r < 4; ++r)
+                            if (kt * 16 + 4 * g + r < N) ap[r] = s[kt][r] * inv;
+                    }
                 }
             }
         }

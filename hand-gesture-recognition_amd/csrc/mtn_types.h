@@ -19,6 +19,7 @@ struct f32x3_t { float v; };
 typedef emu::bf16x8 bf16x8_t;
 typedef emu::f32x4 f32x4_t;
 typedef emu::f32x16 f32x16_t;
+struct f32x4u_t { float v[4]; float& operator[](int i) { return v[i]; } };      // 16-byte store at 4-byte alignment
 __device__ inline float bf2f(bf16_t h) { return emu::bf2f(h.v); }
 __device__ inline bf16_t f2bf(float f) {      // round-to-nearest-even, NaN stays NaN
     uint32_t u; std::memcpy(&u, &f, 4);
@@ -32,6 +33,7 @@ __device__ inline bf16_t f2bf(float f) {      // round-to-nearest-even, NaN stay
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));              // 16-byte store at 4-byte alignment
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h.v << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {   // v_cvt_pk_bf16_f32: RNE, keeps NaN
     bf16_t r; r.v = __builtin_bit_cast(unsigned short, (__bf16)f); return r;
