@@ -178,7 +178,9 @@ def _train_steps(be, name, golden_dir, dtype, nsteps, tol_w, use_graph=False):
         d = (p.detach().cpu() - sd_o[k]).abs()
         bad += int((d > 0.1 * lr * nsteps).sum())
         tot += d.numel()
-        assert abs(float(p.double().norm()) / float(sd_o[k].double().norm()) - 1) < 1e-4, k
+        # (one flipped element of a 64-element affine vector moves its norm by 2 lr |x| / |x|^2 ~ 2.5e-4: the small
+        #  tensors get room for two such elements, the large ones average them out)
+        assert abs(float(p.double().norm()) / float(sd_o[k].double().norm()) - 1) < (5e-4 if p.numel() <= 1024 else 1e-4), k
     assert bad / tot < 5e-3, (bad, tot)
     if nsteps == 1:
         names = [str(n) for n in g["param_names"]]
