@@ -97,6 +97,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
         }
         return;
     }
+    if (mode == 0 && taps == 9) {
+        // dst[o][tap][i] of a 3x3 kernel: one thread per (o, i) reads its nine taps -- 36 contiguous bytes, the wave 2.3 KB
+        // in a row -- and writes one value per tap, each tap's 64 lanes side by side (the element-wise form below walks the
+        // source with a 36-byte stride nine separate times: 4.4x the bytes, profiles/r03_per_kernel_hbm_v3.txt)
+        const int pairs = O * I;
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += gridDim.x * blockDim.x) {
+            const int o = (int)((unsigned)idx / (unsigned)I), i = idx - o * I;
+            const float* sp = src + so + (long)idx * 9;
+            const float f = sc ? sc[o] : 1.0f;
+            float v[9];
+            MTN_UNROLL for (int t = 0; t < 9; ++t) v[t] = sp[t];
+            MTN_UNROLL for (int t = 0; t < 9; ++t) put((long)9 * I, o, t * I + i, v[t] * f);
+        }
+        return;
+    }
     // inner = the destination's fastest axis (I for [o][tap][i], O for [i][tap][o]); one runtime division
     // per element (by inner), the tap split is by a literal 1 or 9 (the model's kernels), generic otherwise
     const int inner = mode == 0 ? I : O;
