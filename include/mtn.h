@@ -300,7 +300,12 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  * keys 4-14: tile / split / kernel-choice overrides of the tuning tools (tools/bench_kernels.py);
  * key 15 = dgrad2 (all four parities of a 3x3 stride-2 data gradient per workgroup; 0: igemm's
  *          parity-major rows); key 16 = igemm image tiles (bit 0 on, bit 1 ignore the tile-count floor);
- * key 18 = kernel-row tiles of the 64-channel 3x3 weight gradient (0: one tap per tile).
+ * key 18 = kernel-row tiles of the 64-channel 3x3 weight gradient (0: one tap per tile);
+ * key 3 = 7 / 8 and key 6 = 4 / 5 / 6: measured-and-rejected igemm pipelines kept for their tests (ping-pong wave
+ *          halves, weights through registers, 256x128 tiles: DESIGN.md section 7d); keys 19 / 20: split-bf16 tile /
+ *          LDS-stage variants; key 21 = stem backward on split-bf16 products.
+ * Every key is refused (MTN_ERR_BAD_ARG, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
+ * call into the library: the product path has no mutable configuration.
  * The environment variable MTN_DEBUG_KEYS="k=v,k=v" applies keys when the binding loads the library.
  * mtn_debug_read: key 1 = in-kernel phase stamps of the last igemm launch (diagnostic builds with
  * -DMTN_STAMPS only; returns non-zero otherwise). */
