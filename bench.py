@@ -1,6 +1,7 @@
 """bench.py -- images/sec of one MultiTaskNet training step (BASELINE.json metric).
 
-  python bench.py [--gpus N --steps K --warmup W]       (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]       (N > 1: under torch.distributed.run, or plain -- it then starts
+                                                         its own N ranks as a child torch.distributed.run)
 
 A "step" = forward + 0.001*CE + JointsMSE + backward (+ RCCL gradient all-reduce) + AdamW on one
 synthetic batch already resident in HBM; workload = BASELINE.json configs[1]: MultiTaskNet
@@ -339,8 +340,24 @@ def cpu_baseline(size, want_ref):
                       f"(torch-CPU ops), {threads} threads of {os.cpu_count()} logical CPUs"}, ref
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves as a CHILD process
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relay its output and return its exit code.
+    The parent never touches the GPU and never exec()s; under torch.distributed.run (WORLD_SIZE set) this is not used."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))                      # (before anything initialises the GPU in this process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,7 +373,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

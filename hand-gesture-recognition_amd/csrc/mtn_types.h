@@ -178,6 +178,16 @@ template <> struct Mma<f32x3_t> {
     typedef Frag3 Frag;
     static __device__ __forceinline__ Frag split(const float* x) {       // 8 values
         Frag f;
+#if defined(MTN_X3_FAKE) && !defined(MTN_EMU)
+        // timing-only diagnostic build (wrong numerics): the fragment is the raw bits, no conversion -- the upper bound
+        // of what storing the operands pre-split can gain
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 a, b;
+        MTN_UNROLL for (int j = 0; j < 4; ++j) { a[j] = __float_as_uint(x[j]); b[j] = __float_as_uint(x[4 + j]); }
+        f.hi = __builtin_bit_cast(bf16x8_t, a);
+        f.lo = __builtin_bit_cast(bf16x8_t, b);
+        return f;
+#endif
 #ifdef MTN_EMU
         MTN_UNROLL for (int j = 0; j < 8; ++j) {
             const bf16_t h = f2bf(x[j]);

@@ -19,9 +19,26 @@ EMU_LIB = os.environ.get("MTN_EMU_LIB") or os.path.join(ROOT, "hand-gesture-reco
 _built = {}
 
 
+def build_emu():
+    """make emu under an exclusive file lock: the xdist controller calls this once before it starts its workers
+    (tests/conftest.py pytest_configure), so that six workers never run `make` into the same build/*.o at once; a
+    worker that still gets here (a run without the controller hook) queues on the lock and finds the build current."""
+    import fcntl
+    if os.environ.get("MTN_EMU_LIB"):
+        return
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    with open(os.path.join(CSRC, "build", ".emu.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-C", CSRC, "-j4", "emu"], check=True, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def _ensure_emu():
-    if "emu" not in _built and not os.environ.get("MTN_EMU_LIB"):
-        subprocess.run(["make", "-C", CSRC, "-j4", "emu"], check=True, stdout=subprocess.DEVNULL)
+    if "emu" not in _built:
+        if os.environ.get("MTN_EMU_BUILT") != "1":      # (set by the controller after its build: workers do not rebuild)
+            build_emu()
         _built["emu"] = True
 
 

@@ -24,6 +24,12 @@ def pytest_xdist_auto_num_workers(config):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "x3: fp32 tensors multiplied in split-bf16 mode (MTN_DTYPE_F32X3)")
+    # the CPU kernel-executor library is built ONCE, here in the controller, before any xdist worker exists
+    # (workers inherit MTN_EMU_BUILT and skip their own `make`: no concurrent builds into one object directory)
+    if not hasattr(config, "workerinput") and os.environ.get("MTN_EMU_BUILT") != "1":
+        import backend
+        backend.build_emu()
+        os.environ["MTN_EMU_BUILT"] = "1"
 
 
 @pytest.fixture(autouse=True)

@@ -175,10 +175,12 @@ def test_overlapped_allreduce_two_ranks_on_the_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_two_rank_code_path_rehearsal():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_rank_code_path_rehearsal(launcher):
     """bench.py's N > 1 path (rank-dependent shards, barrier + max-over-ranks timing, per-rank / exposed-communication
-    figures, the instrumented roofline step on every rank) launched exactly as the driver launches it, with gloo
-    standing in for RCCL because this box has one GPU (MTN_BENCH_BACKEND, bench.py)."""
+    figures, the instrumented roofline step on every rank) with gloo standing in for RCCL because this box has one GPU
+    (MTN_BENCH_BACKEND, bench.py).  ``self``: plain ``python bench.py --gpus 2`` -- the shape of the driver's N = 1 command --
+    which must start its own ranks as a child process; ``torchrun``: wrapped in torch.distributed.run by the caller."""
     import json
     import socket
     import subprocess
@@ -187,9 +189,15 @@ def test_bench_two_rank_code_path_rehearsal():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MTN_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
-                        "--warmup", "2", "--windows", "1"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "1"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -200,3 +208,15 @@ def test_bench_two_rank_code_path_rehearsal():
     assert rk["backend"] == "gloo" and len(rk["ms_per_step_per_rank"]) == 2 and rk["buckets"] == 5
     assert rk["gradient_bytes_all_reduced"] == 7409000 * 4 and rk["comm_exposed_ms"] >= 0
     assert out["roofline"]["launches_per_step"] == 69
+
+
+def test_bench_self_launch_propagates_failure():
+    """`python bench.py --gpus N` with no launcher starts its ranks as a child and exits with the child's status: here the
+    ranks die at once (no GPU in the build container / a bad flag), and the parent must report that, not hang or pass."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "7"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr or "Error" in r.stderr
