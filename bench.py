@@ -93,14 +93,14 @@ def igemm_roofline(step, batch):
         Cin, Cout, M = x.shape[-1], y.shape[-1], y.numel() // y.shape[-1]
         return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y), k
 
-    def g_dgrad(dy, wt, dx, res, k, s, bn=None):
+    def g_dgrad(dy, wt, dx, res, k, s, bn=None, **kw):
         Cout, Cin, Mout = dy.shape[-1], dx.shape[-1], dy.numel() // dy.shape[-1]
         # (a launch that also writes the BatchNorm-backward sums of the next unit reads that unit's raw output too)
         extra = (bn[0], bn[1]) if bn is not None else ()
         # 3x3 stride-2 data gradients run dgrad2_kernel, not the igemm template: their own family below
         return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res, *extra), (32 if (k == 3 and s == 2) else k)
 
-    def g_lin(x, w, out, bias=None, act=0, aux_out=None, res=None):
+    def g_lin(x, w, out, bias=None, act=0, aux_out=None, res=None, **kw):
         K, N = x.shape[-1], out.shape[-1]
         M = x.numel() // K
         return 2.0 * M * N * K, nbytes(x, w, out, aux_out, res), 1

@@ -27,14 +27,16 @@ constexpr int HD = 32;                       // head_dim (model/multitasknet.py:
 // LDS row pitch: bf16 rows are padded by 16 bytes (conflict-free fragment reads); the fp32
 // validation mode keeps rows unpadded so that K and V of a 577-token head (384x384) still fit.
 template <class T> struct Lay { static constexpr int PITCH = sizeof(T) == 2 ? HD + 8 : HD; };
-// split-bf16 mode: fp32 rows padded by 16 bytes (its fragments are 16-byte reads like the bf16 mode's; sequences whose
-// padded K / V no longer fit LDS run the exact-f32 kernels instead, check below)
-template <> struct Lay<f32x3_t> { static constexpr int PITCH = HD + 4; };
+// split storage: a head's row is ONE 32-channel block [32 hi][32 lo] = 128 bytes, kept unpadded (577-token heads fit) with its
+// eight 16-byte slots XOR-swizzled by row & 7 on the way into LDS: the row fragments (slots g and g + 4) and the transposing
+// column reads of acc_mma are then conflict-free like the padded bf16 rows
+template <> struct Lay<f32x3_t> { static constexpr int PITCH = HD; };
 
 // ---- operand over the head_dim axis of one row (A: [row][k], B: [k][col]) ----------------------
 template <class T> struct RowOp;
 template <> struct RowOp<bf16_t> {
     bf16x8_t f;
+    __device__ __forceinline__ void load_lds(const bf16_t* tile, int r, int g) { load(tile + r * Lay<bf16_t>::PITCH, true, g); }
     __device__ __forceinline__ void load(const bf16_t* row, bool valid, int g) {
         chunk16 c = valid ? *reinterpret_cast<const chunk16*>(row + 8 * g) : zero_chunk();
 #ifdef MTN_EMU
@@ -46,18 +48,26 @@ template <> struct RowOp<bf16_t> {
 };
 template <> struct RowOp<float> {
     float f[8];
+    __device__ __forceinline__ void load_lds(const float* tile, int r, int g) { load(tile + r * Lay<float>::PITCH, true, g); }
     __device__ __forceinline__ void load(const float* row, bool valid, int g) {
         MTN_UNROLL for (int ks = 0; ks < 8; ++ks) f[ks] = valid ? row[ks * 4 + g] : 0.f;
     }
 };
-// fp32 storage, split-bf16 products (Mma<f32x3_t>, mtn_types.h): lane group g holds k = 8g .. 8g+7 of its row
+// split storage (Mma<f32x3_t>, mtn_types.h): lane group g holds the hi and lo halves of k = 8g .. 8g+7 of its row, as stored
 template <> struct RowOp<f32x3_t> {
     Frag3 f;
+    // a row in global memory: one unswizzled block [32 hi][32 lo]
     __device__ __forceinline__ void load(const f32x3_t* row, bool valid, int g) {
-        const chunk16* q = reinterpret_cast<const chunk16*>(row + 8 * g);
-        const chunk16 c0 = valid ? q[0] : zero_chunk(), c1 = valid ? q[1] : zero_chunk();
-        f = Mma<f32x3_t>::split2(c0, c1);
+        const chunk16 h = valid ? *reinterpret_cast<const chunk16*>(row + 4 * g) : zero_chunk();
+        const chunk16 l = valid ? *reinterpret_cast<const chunk16*>(row + 16 + 4 * g) : zero_chunk();
+#ifdef MTN_EMU
+        std::memcpy(&f.hi, &h, 16); std::memcpy(&f.lo, &l, 16);
+#else
+        f.hi = __builtin_bit_cast(bf16x8_t, h); f.lo = __builtin_bit_cast(bf16x8_t, l);
+#endif
     }
+    // row r of a staged tile: slots swizzled by r & 7 (stage_heads)
+    __device__ __forceinline__ void load_lds(const f32x3_t* tile, int r, int g) { f = RowFrag<f32x3_t>::load(tile + r * HD, 0, g, r & 7); }
 };
 __device__ __forceinline__ f32x4_t mma32(const RowOp<f32x3_t>& a, const RowOp<f32x3_t>& b, f32x4_t c) {
     return Mma<f32x3_t>::mma(a.f, b.f, c);
@@ -102,8 +112,9 @@ template <> __device__ __forceinline__ float dot_rowops<bf16_t>(const RowOp<bf16
 // two accumulator tiles t0 (rows 0..15) and t1 (rows 16..31) in MFMA C/D layout (row 4g+j, col
 // lane&15) and `col` points at [row0][c0] of a row-major LDS tile.  The k order inside the step
 // is the accumulators' own: slot (g, j) <-> row 4g+j (j<4) / 16+4g+(j-4).
-__device__ __forceinline__ f32x4_t acc_mma(const bf16_t* col, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+__device__ __forceinline__ f32x4_t acc_mma(const bf16_t* rows, int c0, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
     const int g = lane >> 4, i = lane & 15;
+    const bf16_t* col = rows + c0;
     const bf16_t* p0 = col + (4 * g + (i >> 2)) * pitch + 4 * (i & 3);
     const bf16_t* p1 = p0 + 16 * pitch;
     bf16x8_t a, b;
@@ -120,24 +131,47 @@ __device__ __forceinline__ f32x4_t acc_mma(const bf16_t* col, int pitch, f32x4_t
 #endif
     return Mma<bf16_t>::mma(a, b, out);
 }
-__device__ __forceinline__ f32x4_t acc_mma(const float* col, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+__device__ __forceinline__ f32x4_t acc_mma(const float* rows, int c0, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
     const int g = lane >> 4, i = lane & 15;
+    const float* col = rows + c0;
     MTN_UNROLL for (int j = 0; j < 4; ++j) out = Mma<float>::mma(col[(4 * g + j) * pitch + i], t0[j], out);
     MTN_UNROLL for (int j = 0; j < 4; ++j) out = Mma<float>::mma(col[(16 + 4 * g + j) * pitch + i], t1[j], out);
     return out;
 }
 
-__device__ __forceinline__ f32x4_t acc_mma(const f32x3_t* col, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+// split storage: the column operand is read as stored -- transposing reads down the hi and the lo halves of the (swizzled)
+// rows -- and only the accumulator operand, a value computed in registers, is split here
+__device__ __forceinline__ f32x4_t acc_mma(const f32x3_t* rows, int c0, int pitch, f32x4_t t0, f32x4_t t1, f32x4_t out, int lane) {
+    (void)pitch;                                                   // rows of HD elements = 128 bytes
     const int g = lane >> 4, i = lane & 15;
-    const float* c = reinterpret_cast<const float*>(col);
-    float a[8], b[8];
-    MTN_UNROLL for (int j = 0; j < 4; ++j) {
-        a[j] = c[(4 * g + j) * pitch + i];
-        a[4 + j] = c[(16 + 4 * g + j) * pitch + i];
-        b[j] = t0[j];
-        b[4 + j] = t1[j];
-    }
-    return Mma<f32x3_t>::mma(Mma<f32x3_t>::split(a), Mma<f32x3_t>::split(b), out);
+    const int r = 4 * g + (i >> 2), ch = c0 + 4 * (i & 3);         // rows r and r + 16 (the same r & 7), channels ch .. ch+3
+    const char* base = reinterpret_cast<const char*>(rows) + r * 128 + ((ch & 7) << 1);
+    const int sh = (((ch >> 3) ^ (r & 7)) << 4), sl = ((((ch >> 3) + 4) ^ (r & 7)) << 4);
+    Frag3 a;
+    float b[8];
+    MTN_UNROLL for (int j = 0; j < 4; ++j) { b[j] = t0[j]; b[4 + j] = t1[j]; }
+#ifdef MTN_EMU
+    emu::u16x4 u = emu::ds_read_tr16_b64(reinterpret_cast<const bf16_t*>(base + sh)), v = emu::ds_read_tr16_b64(reinterpret_cast<const bf16_t*>(base + sh + 16 * 128));
+    emu::u16x4 ul = emu::ds_read_tr16_b64(reinterpret_cast<const bf16_t*>(base + sl)), vl = emu::ds_read_tr16_b64(reinterpret_cast<const bf16_t*>(base + sl + 16 * 128));
+    MTN_UNROLL for (int j = 0; j < 4; ++j) { a.hi[j] = u[j]; a.hi[4 + j] = v[j]; a.lo[j] = ul[j]; a.lo[4 + j] = vl[j]; }
+#else
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
+    const bf16x4_t u = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + sh));
+    const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + sh + 16 * 128));
+    const bf16x4_t ul = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + sl));
+    const bf16x4_t vl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + sl + 16 * 128));
+    a.hi = __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7);
+    a.lo = __builtin_shufflevector(ul, vl, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+    return Mma<f32x3_t>::mma(a, Mma<f32x3_t>::split(b), out);
+}
+
+// an accumulator quad -> four consecutive channels c .. c+3 of an output row
+template <class T> __device__ __forceinline__ void st4v(T* row, int c, const f32x4_t& q) {
+    float v[4];
+    MTN_UNROLL for (int e = 0; e < 4; ++e) v[e] = q[e];
+    st4<T>(row, c, v);
 }
 
 // stage rows [0, NP) x 32 of one head (column offset `coff` of a [B*N][ld] tensor) into LDS, zero padded
@@ -160,8 +194,10 @@ __device__ __forceinline__ void stage_heads(T* dst0, const T* __restrict__ src0,
         MTN_UNROLL for (int j = 0; j < NB; ++j) {
             const int i = base + j * nt, r = i / CPR, c = (i - r * CPR) * VEC;
             if (i < total) {
-                *reinterpret_cast<chunk16*>(dst0 + r * PITCH + c) = a[j];
-                *reinterpret_cast<chunk16*>(dst1 + r * PITCH + c) = b[j];
+                // (split storage: the 16-byte slot index is swizzled by the row, see Lay<f32x3_t>)
+                const int cd = std::is_same<T, f32x3_t>::value ? (((c / VEC) ^ (r & 7)) * VEC) : c;
+                *reinterpret_cast<chunk16*>(dst0 + r * PITCH + cd) = a[j];
+                *reinterpret_cast<chunk16*>(dst1 + r * PITCH + cd) = b[j];
             }
         }
     }
@@ -222,7 +258,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         MTN_UNROLL for (int kt = 0; kt < MAXT; ++kt) {
             if (FULL || kt < nkt) {
                 RowOp<T> kf;
-                kf.load(sK + (kt * 16 + li) * PITCH, true, g);
+                kf.load_lds(sK, kt * 16 + li, g);
                 s[kt] = mma32(kf, qf, zero4());
             }
         }
@@ -273,15 +309,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ qkv
         f32x4_t o0 = zero4(), o1 = zero4();
         MTN_UNROLL for (int pr = 0; pr < MAXT / 2; ++pr) {
             if (FULL || 2 * pr < nkt) {
-                o0 = acc_mma(sV + pr * 32 * PITCH, PITCH, s[2 * pr], s[2 * pr + 1], o0, lane);
-                o1 = acc_mma(sV + pr * 32 * PITCH + 16, PITCH, s[2 * pr], s[2 * pr + 1], o1, lane);
+                o0 = acc_mma(sV + pr * 32 * PITCH, 0, PITCH, s[2 * pr], s[2 * pr + 1], o0, lane);
+                o1 = acc_mma(sV + pr * 32 * PITCH, 16, PITCH, s[2 * pr], s[2 * pr + 1], o1, lane);
             }
         }
         MTN_UNROLL for (int r = 0; r < 4; ++r) { o0[r] *= inv; o1[r] *= inv; }
         if (qok) {      // O^T tiles: rows d = dt*16 + 4g + r, column q
-            T* op = out + (row0 + q) * (H * HD) + h * HD + 4 * g;
-            store4<T>(op, o0);
-            store4<T>(op + 16, o1);
+            T* op = out + (row0 + q) * (H * HD) + h * HD;
+            st4v<T>(op, 4 * g, o0);
+            st4v<T>(op, 16 + 4 * g, o1);
         }
     }
 }
@@ -339,8 +375,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
                 ds[u] = zero4();
                 if (kt < MAXT && (FULL || kt < nkt)) {
                     RowOp<T> kf, vf;
-                    kf.load(sK + (kt * 16 + li) * PITCH, true, g);
-                    vf.load(sV + (kt * 16 + li) * PITCH, true, g);
+                    kf.load_lds(sK, kt * 16 + li, g);
+                    vf.load_lds(sV, kt * 16 + li, g);
                     const f32x4_t s = mma32(kf, qf, zero4());
                     const f32x4_t dp = mma32(vf, dof, zero4());
                     MTN_UNROLL for (int r = 0; r < 4; ++r) {
@@ -356,16 +392,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
             MTN_UNROLL for (int u = 0; u < GK; u += 2) {
                 const int pr = (k0 + u) / 2;                       // (the padded tile count is even: pairs are complete)
                 if (k0 + u < MAXT && (FULL || 2 * pr < nkt)) {
-                    d0 = acc_mma(sK + pr * 32 * PITCH, PITCH, ds[u], ds[u + 1], d0, lane);
-                    d1 = acc_mma(sK + pr * 32 * PITCH + 16, PITCH, ds[u], ds[u + 1], d1, lane);
+                    d0 = acc_mma(sK + pr * 32 * PITCH, 0, PITCH, ds[u], ds[u + 1], d0, lane);
+                    d1 = acc_mma(sK + pr * 32 * PITCH, 16, PITCH, ds[u], ds[u + 1], d1, lane);
                 }
             }
             if (FULL) MTN_SCHED_FENCE();
         }
         if (qok) {
-            T* dp = dqkv + (row0 + q) * ld + h * HD + 4 * g;
-            store4<T>(dp, d0);
-            store4<T>(dp + 16, d1);
+            T* dp = dqkv + (row0 + q) * ld + h * HD;
+            st4v<T>(dp, 4 * g, d0);
+            st4v<T>(dp, 16 + 4 * g, d1);
         }
     }
 }
@@ -416,8 +452,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
             MTN_UNROLL for (int hf = 0; hf < 2; ++hf) {
                 const int qb = qp * 32 + hf * 16;
                 RowOp<T> qa, da;                          // A operands: rows = queries
-                qa.load(sQ + (qb + li) * PITCH, true, g);
-                da.load(sD + (qb + li) * PITCH, true, g);
+                qa.load_lds(sQ, qb + li, g);
+                da.load_lds(sD, qb + li, g);
                 const f32x4_t s = mma32(qa, kf, zero4());       // S[q = qb+4g+r][key]
                 const f32x4_t dp = mma32(da, vf, zero4());      // dP[q][key]
                 // (padded queries need no mask: their Q and dO rows are zero in LDS, so they add nothing to
@@ -431,16 +467,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
                     ds[hf][r] = pv * (dp[r] - dq) * scale;
                 }
             }
-            dv0 = acc_mma(sD + qp * 32 * PITCH, PITCH, p[0], p[1], dv0, lane);          // dV^T += dO^T P
-            dv1 = acc_mma(sD + qp * 32 * PITCH + 16, PITCH, p[0], p[1], dv1, lane);
-            dk0 = acc_mma(sQ + qp * 32 * PITCH, PITCH, ds[0], ds[1], dk0, lane);        // dK^T += Q^T dS
-            dk1 = acc_mma(sQ + qp * 32 * PITCH + 16, PITCH, ds[0], ds[1], dk1, lane);
+            dv0 = acc_mma(sD + qp * 32 * PITCH, 0, PITCH, p[0], p[1], dv0, lane);          // dV^T += dO^T P
+            dv1 = acc_mma(sD + qp * 32 * PITCH, 16, PITCH, p[0], p[1], dv1, lane);
+            dk0 = acc_mma(sQ + qp * 32 * PITCH, 0, PITCH, ds[0], ds[1], dk0, lane);        // dK^T += Q^T dS
+            dk1 = acc_mma(sQ + qp * 32 * PITCH, 16, PITCH, ds[0], ds[1], dk1, lane);
         }
         if (kok) {
-            T* dkp = dqkv + (row0 + key) * ld + H * HD + h * HD + 4 * g;
-            T* dvp = dqkv + (row0 + key) * ld + 2 * H * HD + h * HD + 4 * g;
-            store4<T>(dkp, dk0); store4<T>(dkp + 16, dk1);
-            store4<T>(dvp, dv0); store4<T>(dvp + 16, dv1);
+            T* dkp = dqkv + (row0 + key) * ld + H * HD + h * HD;
+            T* dvp = dqkv + (row0 + key) * ld + 2 * H * HD + h * HD;
+            st4v<T>(dkp, 4 * g, dk0); st4v<T>(dkp, 16 + 4 * g, dk1);
+            st4v<T>(dvp, 4 * g, dv0); st4v<T>(dvp, 16 + 4 * g, dv1);
         }
     }
 }
@@ -496,7 +532,7 @@ int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
     return mtn_check_launch("attn_bwd_dkv");
 }
 
-// split-bf16 mode where its padded K / V (or Q / dO) tiles fit LDS, exact-f32 kernels (unpadded rows) beyond that
+// split storage: unpadded 128-byte rows like the exact-f32 kernels, so every sequence those accept fits
 bool attn_x3_fits(int N) {
     const int NP = (N + 31) & ~31;
     return 2 * (size_t)NP * Lay<f32x3_t>::PITCH * sizeof(float) <= 160 * 1024;
@@ -505,6 +541,9 @@ bool attn_x3_fits(int N) {
 int check_attn(const AttnArgs& a, int dtype) {
     MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "attention: bad dtype");
     MTN_REQUIRE(a.B > 0 && a.H > 0 && a.N > 0 && a.D == HD, "attention: head_dim must be %d (got %d)", HD, a.D);
+    // (the softmax takes its row maximum over the RAW scores and folds the scale into the exponent: a negative scale would
+    //  pick the wrong extreme, a zero scale would un-mask the padded keys)
+    MTN_REQUIRE(a.scale > 0.f && a.scale < 3.0e38f, "attention: scale must be positive and finite (got %g)", (double)a.scale);
     const int NP = (a.N + 31) & ~31;
     MTN_REQUIRE(NP / 16 <= 38, "attention: N=%d exceeds the register-resident limit 608", a.N);
     const size_t lds = dtype == MTN_BF16 ? 2 * (size_t)NP * (HD * 2 + 16) + 2 * (size_t)NP * 4 : 2 * (size_t)NP * HD * 4;

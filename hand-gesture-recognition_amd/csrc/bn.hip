@@ -138,7 +138,7 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ ss,
                                                          const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
                                                          int M, int C, int act) {
-    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int VEC = Ev<T>::N;
     const int cpr = C / VEC;
     const int gtid = blockIdx.x * 256 + threadIdx.x;
     const int c = (gtid % cpr) * VEC;
@@ -147,17 +147,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     k.load(ss, C, c);
     for (int m = gtid / cpr; m < M; m += rstep) {
         float v[VEC];
-        unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
+        ld_vec<T>(y + (long)m * ldy, c, v);
         MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * k.a[e] + k.b[e];
         if (res) {
             float r[VEC];
-            unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
+            ld_vec<T>(res + (long)m * ldr, c, r);
             MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += r[e];
         }
         if (act == MTN_ACT_SILU) {
             MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = siluf_(v[e]);
         }
-        *reinterpret_cast<chunk16*>(out + (long)m * ldo + c) = pack<T>(v);
+        st_vec<T>(out + (long)m * ldo, c, v);
     }
 }
 
@@ -167,10 +167,10 @@ __device__ __forceinline__ void bn_dz(const T* __restrict__ dout, int lddo, cons
                                       const T* __restrict__ res, int ldr, const ChanConst<VEC>& ss,
                                       const ChanConst<VEC>& mr, int act, int m, int c, float* dz, float* xh) {
     float g[VEC], v[VEC], r[VEC];
-    unpack<T>(*reinterpret_cast<const chunk16*>(dout + (long)m * lddo + c), g);
-    unpack<T>(*reinterpret_cast<const chunk16*>(y + (long)m * ldy + c), v);
+    ld_vec<T>(dout + (long)m * lddo, c, g);
+    ld_vec<T>(y + (long)m * ldy, c, v);
     const bool with_res = act == MTN_ACT_SILU && res;
-    if (with_res) unpack<T>(*reinterpret_cast<const chunk16*>(res + (long)m * ldr + c), r);
+    if (with_res) ld_vec<T>(res + (long)m * ldr, c, r);
     bn_dz_math<VEC>(g, v, r, with_res, ss.a, ss.b, mr.a, mr.b, act == MTN_ACT_SILU, dz, xh);
 }
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ ss, const float* __restrict__ mr,
                                                             int M, int C, int act, int rows_per_block,
                                                             float* __restrict__ partial) {
-    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int VEC = Ev<T>::N;
     MTN_DYN_SMEM(smem);
     float* red = reinterpret_cast<float*>(smem);        // [rl][2][C]
     const int cpr = C / VEC;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ coef, T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dres, int lddres, const T* __restrict__ extra,
                                                            int ldextra, int M, int C, int act) {
-    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int VEC = Ev<T>::N;
     const int cpr = C / VEC;
     const int gtid = blockIdx.x * 256 + threadIdx.x;
     const int c = (gtid % cpr) * VEC;
@@ -251,14 +251,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float dz[VEC], xh[VEC], o[VEC];
         bn_dz<T, VEC>(dout, lddo, y, ldy, res, ldr, kss, kmr, act, m, c, dz, xh);
         MTN_UNROLL for (int e = 0; e < VEC; ++e) o[e] = kss.a[e] * (dz[e] - kco.a[e] - xh[e] * kco.b[e]);
-        *reinterpret_cast<chunk16*>(dy + (long)m * lddy + c) = pack<T>(o);
+        st_vec<T>(dy + (long)m * lddy, c, o);
         if (dres) {          // gradient of the residual input (= dz, the pre-activation gradient)
             if (extra) {
                 float x[VEC];
-                unpack<T>(*reinterpret_cast<const chunk16*>(extra + (long)m * ldextra + c), x);
+                ld_vec<T>(extra + (long)m * ldextra, c, x);
                 MTN_UNROLL for (int e = 0; e < VEC; ++e) dz[e] += x[e];
             }
-            *reinterpret_cast<chunk16*>(dres + (long)m * lddres + c) = pack<T>(dz);
+            st_vec<T>(dres + (long)m * lddres, c, dz);
         }
     }
 }
@@ -326,14 +326,20 @@ int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, c
 
 int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res, int ldr, void* out, int ldo, int dtype,
                        int M, int C, int act, hipStream_t stream) {
-    const int vec = dtype == MTN_BF16 ? 8 : 4;
+    const int vec = dtype == MTN_F32 ? 4 : 8;
     MTN_REQUIRE(C % vec == 0 && ldy % vec == 0 && ldo % vec == 0 && (!res || ldr % vec == 0), "bn_act_fwd: alignment");
+    MTN_REQUIRE(dtype != MTN_F32X3 || (C % 32 == 0 && ldy % 32 == 0 && ldo % 32 == 0 && (!res || ldr % 32 == 0) &&
+                                       ((uintptr_t)y | (uintptr_t)out | (uintptr_t)res) % 16 == 0),
+                "bn_act_fwd: split storage needs whole 32-channel blocks (C, row pitches) and 16-byte aligned operands");
     MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "bn_act_fwd: act=%d", act);
     MTN_REQUIRE(C / vec <= 256 && 256 % (C / vec) == 0, "bn_act_fwd: C=%d unsupported (16-byte chunks per row must divide 256)", C);
     const long total = (long)M * (C / vec);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_act_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16_t*)y, ldy, ss,
                    (const bf16_t*)res, ldr, (bf16_t*)out, ldo, M, C, act);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(bn_act_fwd_kernel<f32x3_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const f32x3_t*)y, ldy, ss,
+                   (const f32x3_t*)res, ldr, (f32x3_t*)out, ldo, M, C, act);
     else
         MTN_LAUNCH(bn_act_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)y, ldy, ss,
                    (const float*)res, ldr, (float*)out, ldo, M, C, act);
@@ -347,9 +353,13 @@ int mtn_bn_bwd_blocks(int M) {
 }
 
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
-    const int vec = dtype == MTN_BF16 ? 8 : 4;
+    const int vec = dtype == MTN_F32 ? 4 : 8;
     const int cpr = a.C / vec;
     MTN_REQUIRE(a.C % vec == 0 && cpr <= 256 && 256 % cpr == 0, "bn_bwd: C=%d unsupported", a.C);
+    MTN_REQUIRE(dtype != MTN_F32X3 || (a.C % 32 == 0 && a.lddo % 32 == 0 && a.ldy % 32 == 0 && a.lddy % 32 == 0 && (!a.res || a.ldr % 32 == 0) &&
+                                       (!a.dres || a.lddres % 32 == 0) && (!a.extra || a.ldextra % 32 == 0) &&
+                                       ((uintptr_t)a.dout | (uintptr_t)a.y | (uintptr_t)a.res | (uintptr_t)a.dy | (uintptr_t)a.dres | (uintptr_t)a.extra) % 16 == 0),
+                "bn_bwd: split storage needs whole 32-channel blocks (C, row pitches) and 16-byte aligned operands");
     MTN_REQUIRE(a.act == MTN_ACT_NONE || a.act == MTN_ACT_SILU, "bn_bwd: act=%d", a.act);
     MTN_REQUIRE(a.act == MTN_ACT_SILU || !a.res, "bn_bwd: residual needs SiLU");
     MTN_REQUIRE(a.partial_rows >= 0, "bn_bwd: partial_rows=%d", a.partial_rows);
@@ -361,6 +371,10 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
     } else if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)a.dout, a.lddo,
                    (const bf16_t*)a.y, a.ldy, (const bf16_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
+                   rows_per_block, a.partial);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(bn_bwd_reduce_kernel<f32x3_t>, dim3(blocks), dim3(256), lds, stream, (const f32x3_t*)a.dout, a.lddo,
+                   (const f32x3_t*)a.y, a.ldy, (const f32x3_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.M, a.C, a.act,
                    rows_per_block, a.partial);
     else
         MTN_LAUNCH(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), lds, stream, (const float*)a.dout, a.lddo,
@@ -381,6 +395,10 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
         MTN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16_t*)a.dout, a.lddo,
                    (const bf16_t*)a.y, a.ldy, (const bf16_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.coef,
                    (bf16_t*)a.dy, a.lddy, (bf16_t*)a.dres, a.lddres, (const bf16_t*)a.extra, a.ldextra, a.M, a.C, a.act);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(bn_bwd_apply_kernel<f32x3_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const f32x3_t*)a.dout, a.lddo,
+                   (const f32x3_t*)a.y, a.ldy, (const f32x3_t*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.coef,
+                   (f32x3_t*)a.dy, a.lddy, (f32x3_t*)a.dres, a.lddres, (const f32x3_t*)a.extra, a.ldextra, a.M, a.C, a.act);
     else
         MTN_LAUNCH(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)a.dout, a.lddo,
                    (const float*)a.y, a.ldy, (const float*)a.res, a.ldr, a.scale_shift, a.mean_rstd, a.coef,

@@ -26,7 +26,7 @@ int mtn_check_launch(const char* what) {
 extern "C" {
 
 const char* mtn_last_error(void) { return g_err; }
-int mtn_abi_version(void) { return 4; }
+int mtn_abi_version(void) { return 5; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
@@ -127,7 +127,7 @@ int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int ld
     p.stats = bn_partial; p.stats_rows = bn_tiles;
     g_handover = {nullptr, 0, 0, 0};
     const int rc2 = mtn_igemm_run(p, dtype, (hipStream_t)stream);
-    if (rc2 == MTN_OK) g_handover = {bn_partial, bn_tiles, Cin, mtn_storage_dtype(dtype)};
+    if (rc2 == MTN_OK) g_handover = {bn_partial, bn_tiles, Cin, dtype};
     return rc2;
 }
 
@@ -229,7 +229,7 @@ int mtn_conv1_stats(const float* x_nchw, const void* w, float* stats, int dtype,
 }
 int mtn_conv1_bn_act(const float* x_nchw, const void* w, const float* scale_shift, void* out, int act, int dtype, int B,
                      int H, int W, void* stream) {
-    return mtn_conv1_bn_act_run(x_nchw, w, scale_shift, out, act, mtn_storage_dtype(dtype), B, H, W, (hipStream_t)stream);
+    return mtn_conv1_bn_act_run(x_nchw, w, scale_shift, out, act, dtype, B, H, W, (hipStream_t)stream);
 }
 int mtn_conv1_bwd_partial_rows(int B, int H, int W) {
     const int blocks = mtn_conv1_bwd_blocks((long)B * (H / 2) * (W / 2));
@@ -240,7 +240,7 @@ int mtn_conv1_bwd_partial_width(void) { return mtn_conv1_bwd_width(); }
 int mtn_conv1_bwd(const float* x_nchw, const void* w, const void* dout, const float* scale_shift, const float* mean_rstd,
                   float* partial, float* dgamma, float* dbeta, float* dw, int act, int dtype, int B, int H, int W,
                   void* stream) {
-    return mtn_conv1_bwd_run(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, dw, act, mtn_storage_dtype(dtype), B, H, W,
+    return mtn_conv1_bwd_run(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, dw, act, dtype, B, H, W,
                              (hipStream_t)stream);
 }
 
@@ -260,7 +260,7 @@ int mtn_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
 
 int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void* res, int ldres, void* out,
                    int ldo, int dtype, int M, int C, int act, void* stream) {
-    return mtn_bn_act_fwd_run(y, ldy, scale_shift, res, ldres, out, ldo, mtn_storage_dtype(dtype), M, C, act, (hipStream_t)stream);
+    return mtn_bn_act_fwd_run(y, ldy, scale_shift, res, ldres, out, ldo, dtype, M, C, act, (hipStream_t)stream);
 }
 
 int mtn_bn_bwd_partial_rows(int M) { return mtn_reduce_rows_needed(mtn_bn_bwd_blocks(M)); }
@@ -275,7 +275,7 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
         g_handover = {nullptr, 0, 0, 0};                // consumed (or refused) exactly once
         MTN_REQUIRE(h.partial != nullptr, "bn_act_bwd: partial_rows=%d but no mtn_conv_dgrad_bn launch on this thread left "
                     "BatchNorm-backward sums (or they were already consumed)", partial_rows);
-        MTN_REQUIRE(h.partial == partial && h.tiles == partial_rows && h.C == C && h.dtype == mtn_storage_dtype(dtype),
+        MTN_REQUIRE(h.partial == partial && h.tiles == partial_rows && h.C == C && h.dtype == dtype,
                     "bn_act_bwd: partial_rows=%d rows of %d channels do not match what the preceding mtn_conv_dgrad_bn "
                     "wrote (%d rows of %d channels%s)", partial_rows, C, h.tiles, h.C, h.partial == partial ? "" : ", another slab");
     }
@@ -284,7 +284,7 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
     a.scale_shift = scale_shift; a.mean_rstd = mean_rstd; a.partial = partial; a.coef = coef;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.lddy = lddy; a.dres = dres; a.lddres = lddres;
     a.extra = extra; a.ldextra = ldextra; a.M = M; a.C = C; a.act = act;
-    return mtn_bn_bwd_run(a, mtn_storage_dtype(dtype), (hipStream_t)stream);
+    return mtn_bn_bwd_run(a, dtype, (hipStream_t)stream);
 }
 
 int mtn_colsum_rows_per_block(void) { return mtn_fold_rows_per_block(); }
@@ -295,28 +295,28 @@ int mtn_colsum_grouped(const void* jobs_l1, int n1, int max_w1, int max_rowblock
 }
 
 int mtn_tokens_fwd(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B, int P, void* stream) {
-    return mtn_tokens_fwd_run(feat, pos, cls, tok, mtn_storage_dtype(dtype), B, P, (hipStream_t)stream);
+    return mtn_tokens_fwd_run(feat, pos, cls, tok, dtype, B, P, (hipStream_t)stream);
 }
 int mtn_tokens_bwd(const void* dtok, void* dfeat, float* dcls, int dtype, int B, int P, void* stream) {
-    return mtn_tokens_bwd_run(dtok, dfeat, dcls, mtn_storage_dtype(dtype), B, P, (hipStream_t)stream);
+    return mtn_tokens_bwd_run(dtok, dfeat, dcls, dtype, B, P, (hipStream_t)stream);
 }
 int mtn_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean_rstd,
                       int dtype, int M, float eps, void* stream) {
-    return mtn_ln_fwd_run(x, ldx, gamma, beta, y, ldy, mean_rstd, mtn_storage_dtype(dtype), M, eps, (hipStream_t)stream);
+    return mtn_ln_fwd_run(x, ldx, gamma, beta, y, ldy, mean_rstd, dtype, M, eps, (hipStream_t)stream);
 }
 int mtn_rowslab_rows(int M) { return mtn_reduce_rows_needed(mtn_rowslab_blocks(M)); }
 int mtn_rowslab_producer_rows(int M) { return mtn_rowslab_blocks(M); }
 int mtn_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma,
                       const void* dres, int lddres, void* dx, int lddx, float* partial, float* dgamma_dbeta, int dtype,
                       int M, void* stream) {
-    return mtn_ln_bwd_run(dy, lddy, x, ldx, mean_rstd, gamma, dres, lddres, dx, lddx, partial, dgamma_dbeta, mtn_storage_dtype(dtype), M,
+    return mtn_ln_bwd_run(dy, lddy, x, ldx, mean_rstd, gamma, dres, lddres, dx, lddx, partial, dgamma_dbeta, dtype, M,
                           (hipStream_t)stream);
 }
 int mtn_gelu_bwd(const void* dh, const void* a, void* da, int dtype, long long n, void* stream) {
-    return mtn_gelu_bwd_run(dh, a, da, mtn_storage_dtype(dtype), (long)n, (hipStream_t)stream);
+    return mtn_gelu_bwd_run(dh, a, da, dtype, (long)n, (hipStream_t)stream);
 }
 int mtn_bias_grad(const void* dy, int lddy, float* partial, float* dbias, int dtype, int M, void* stream) {
-    return mtn_bias_grad_run(dy, lddy, partial, dbias, mtn_storage_dtype(dtype), M, (hipStream_t)stream);
+    return mtn_bias_grad_run(dy, lddy, partial, dbias, dtype, M, (hipStream_t)stream);
 }
 int mtn_attention_fwd(const void* qkv, void* out, float* lse, float* attn, int dtype, int B, int N, int H, int D,
                       float scale, void* stream) {
@@ -334,14 +334,14 @@ int mtn_attention_bwd(const void* qkv, const void* out, const void* dout, const 
 int mtn_cls_head_fwd(const void* tok, long long tok_stride, const float* ln_w, const float* ln_b, const float* W,
                      const float* bias, float* logits, float* xhat, float* mean_rstd, int dtype, int B, int C, float eps,
                      void* stream) {
-    return mtn_cls_head_fwd_run(tok, (long)tok_stride, ln_w, ln_b, W, bias, logits, xhat, mean_rstd, mtn_storage_dtype(dtype), B, C, eps,
+    return mtn_cls_head_fwd_run(tok, (long)tok_stride, ln_w, ln_b, W, bias, logits, xhat, mean_rstd, dtype, B, C, eps,
                                 (hipStream_t)stream);
 }
 int mtn_cls_head_bwd(const float* dlogits, const float* W, const float* ln_w, const float* ln_b, const float* xhat,
                      const float* mean_rstd, void* dtok, long long tok_stride, float* dW, float* dbias, float* dln_w_b,
                      float* partial, int dtype, int B, int C, void* stream) {
     return mtn_cls_head_bwd_run(dlogits, W, ln_w, ln_b, xhat, mean_rstd, dtok, (long)tok_stride, dW, dbias, dln_w_b, partial,
-                                mtn_storage_dtype(dtype), B, C, (hipStream_t)stream);
+                                dtype, B, C, (hipStream_t)stream);
 }
 int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
                       void* stream) {
@@ -364,6 +364,10 @@ int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 int mtn_pack_weights(const float* src, const float* scale, void* dst, const int* desc, int ntensors, int max_elems, int dtype,
                      void* stream) {
     return mtn_pack_run(src, scale, dst, desc, ntensors, max_elems, dtype, (hipStream_t)stream);
+}
+
+int mtn_x3_convert(const void* src, int ld_src, void* dst, int ld_dst, int to_split, long long M, int C, void* stream) {
+    return mtn_x3_convert_run(src, ld_src, dst, ld_dst, to_split, (long)M, C, (hipStream_t)stream);
 }
 
 int mtn_heatmap_argmax(const float* hm, float* preds, float* maxvals, int maps, int H, int W, void* stream) {

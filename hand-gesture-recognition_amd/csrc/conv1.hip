@@ -19,6 +19,7 @@
 //                            dW[c][k] = scale_c ( P[c][k] - m1_c Sa[k] - m2_c rstd_c ( (W G)[c][k] - mean_c Sa[k] ) )
 //                        -- no d raw tensor, no separate BN reduce / apply passes (they were 3 + 2 sweeps
 //                        over 302 MB tensors), and the weight gradient sees un-rounded d raw.
+#include <type_traits>
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
@@ -126,9 +127,10 @@ __global__ __launch_bounds__(PXB) void conv1_fwd_kernel(const float* __restrict_
 // stored; MODE 2: y = act(conv * scale + shift)).  A workgroup walks tiles of 256 pixels; the 27
 // image taps of a thread's NEXT pixel are fetched into registers before the MFMAs / epilogue of the
 // current tile, so the stride-2 fp32 gather (the cost of these HBM-bound passes) overlaps them.
-template <class T, int MODE>
+// S = storage type of the output (T, or split storage f32x3_t over T = float: the tile is staged as f32 and split on the way out)
+template <class T, int MODE, class S = T>
 __global__ __launch_bounds__(PXB) void conv1_fused_kernel(const float* __restrict__ x, const T* __restrict__ w,
-                                                          T* __restrict__ y, float* __restrict__ stats, int B, int H,
+                                                          S* __restrict__ y, float* __restrict__ stats, int B, int H,
                                                           int W, int OH, int OW, const float* __restrict__ ss, int act) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KP = 32;
@@ -229,11 +231,18 @@ __global__ __launch_bounds__(PXB) void conv1_fused_kernel(const float* __restric
                             from_f<T>(act == MTN_ACT_SILU ? siluf_(z) : z);
                     }
             MTN_BARRIER_LDS();
-            constexpr int CPR = CO / VEC;
+            constexpr int EVS = Ev<S>::N, CPR = CO / EVS;
             for (int idx = tid; idx < PXB * CPR; idx += PXB) {
-                const int row = idx / CPR, col = (idx - row * CPR) * VEC;
+                const int row = idx / CPR, col = (idx - row * CPR) * EVS;
                 const unsigned mm = (unsigned)tile * PXB + row;
-                if (mm < M) *reinterpret_cast<chunk16*>(y + (long)mm * CO + col) = *reinterpret_cast<const chunk16*>(sC + row * PC + col);
+                if (mm >= M) continue;
+                if constexpr (std::is_same<S, T>::value) {
+                    *reinterpret_cast<chunk16*>(y + (long)mm * CO + col) = *reinterpret_cast<const chunk16*>(sC + row * PC + col);
+                } else {
+                    float f[EVS];
+                    MTN_UNROLL for (int e = 0; e < EVS; ++e) f[e] = to_f<T>(sC[row * PC + col + e]);
+                    st_vec<S>(y + (long)mm * CO, col, f);
+                }
             }
         }
         MTN_BARRIER_LDS();                                     // red / sC are read before the next tile's patches land
@@ -313,15 +322,16 @@ constexpr int ONE_K = KK;                     // patch slot that carries the con
 // wave w recomputes raw[ch 16w..16w+15][64 px] (weight fragment as the MFMA row operand, loaded once:
 // a lane's quad is 4 consecutive channels of one pixel, so it needs only 4 x 4 BatchNorm constants),
 // forms dz, keeps sum dz*xhat in 4 registers and writes dz to LDS for the pixel contraction.
-template <class T, bool TR, bool SILU>
+template <class T, bool TR, bool SILU, class S = T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ w,
-                                                        const T* __restrict__ dout, const float* __restrict__ ss,
+                                                        const S* __restrict__ dout, const float* __restrict__ ss,
                                                         const float* __restrict__ mr, float* __restrict__ partial, int B,
                                                         int H, int W, int OH, int OW, int px_per_block) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KI = Mma<T>::KI;
     constexpr int PY = CO + 16 / (int)sizeof(T), PA = 32 + 16 / (int)sizeof(T);
-    constexpr int GCH = WPX * (CO / VEC) / 256;                  // d-activation chunks per thread per step (2 / 4)
+    constexpr int EVS = Ev<S>::N;                                // channels per load of the d-activation (split storage: 8)
+    constexpr int GCH = WPX * (CO / EVS) / 256;                  // d-activation loads per thread per step
     __shared__ __attribute__((aligned(16))) T sA[WPX * PA];      // patches [px][32]
     __shared__ __attribute__((aligned(16))) T sB[CO * PA];       // weights [co][32]
     __shared__ __attribute__((aligned(16))) T sG[WPX * PY];      // d activation [px][64]
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv1_bwd_kernel(
         k_sc[r] = ss[c0 + r]; k_sh[r] = ss[CO + c0 + r]; k_rs[r] = rstd; k_b2[r] = -mean * rstd; s2[r] = 0.f;
     }
     // loader state: d-activation chunks (row, column) and the patch slice (pixel tid/4, k = 8*(tid%4) .. +7)
-    chunk16 rg[GCH];
+    RawVec<S> rg[GCH];
     float rv[8];
     const int pr = tid >> 2, pk0 = (tid & 3) * 8;
     // this thread's 8 taps: row / column offset and channel plane (loop invariant)
@@ -357,10 +367,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv1_bwd_kernel(
     }
     auto fetch = [&](unsigned mb) {
         MTN_UNROLL for (int i = 0; i < GCH; ++i) {                // rows past the end: loaded from the last row, zeroed by select
-            const int q = tid + i * 256, r = q / (CO / VEC), c = (q - r * (CO / VEC)) * VEC;
+            const int q = tid + i * 256, r = q / (CO / EVS), c = (q - r * (CO / EVS)) * EVS;
             const unsigned mr_ = mb + r < m1 ? mb + r : m1 - 1;
-            const chunk16 t = *reinterpret_cast<const chunk16*>(dout + (long)mr_ * CO + c);
-            rg[i] = mb + r < m1 ? t : zero_chunk();
+            const RawVec<S> t = ld_raw<S>(dout + (long)mr_ * CO, c);
+            rg[i] = mb + r < m1 ? t : zero_raw<S>();
         }
         // taps are loaded under their validity condition (see the forward gather: measured faster than
         // unconditional loads from clamped addresses + selects)
@@ -382,8 +392,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv1_bwd_kernel(
     };
     auto stage = [&]() {
         MTN_UNROLL for (int i = 0; i < GCH; ++i) {
-            const int q = tid + i * 256, r = q / (CO / VEC), c = (q - r * (CO / VEC)) * VEC;
-            *reinterpret_cast<chunk16*>(sG + r * PY + c) = rg[i];
+            const int q = tid + i * 256, r = q / (CO / EVS), c = (q - r * (CO / EVS)) * EVS;
+            if constexpr (std::is_same<S, T>::value) {
+                *reinterpret_cast<chunk16*>(sG + r * PY + c) = rg[i].c;
+            } else {                                             // split storage -> the f32 tile the math reads
+                float f[EVS];
+                unpack_raw<S>(rg[i], f);
+                MTN_UNROLL for (int e = 0; e < EVS; e += VEC) *reinterpret_cast<chunk16*>(sG + r * PY + c + e) = pack<T>(f + e);
+            }
         }
         MTN_UNROLL for (int c = 0; c < 8; c += VEC) *reinterpret_cast<chunk16*>(sA + pr * PA + pk0 + c) = pack<T>(rv + c);
     };
@@ -511,7 +527,7 @@ int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partia
 static int g_conv1_grid_cap = 0;       // debug key 11: cap on the fused kernels' grid (tests: several tiles per workgroup)
 void mtn_conv1_set_grid_cap(int n) { g_conv1_grid_cap = n > 0 ? n : 0; }
 
-template <class T, int MODE>
+template <class T, int MODE, class S = T>
 static int conv1_fused_launch_t(const float* x, const void* w, void* y, float* stats, const float* ss, int act, int B, int H,
                                 int W, hipStream_t stream) {
     const int OH = H / 2, OW = W / 2;
@@ -526,9 +542,9 @@ static int conv1_fused_launch_t(const float* x, const void* w, void* y, float* s
     if (g_conv1_grid_cap && grid > g_conv1_grid_cap) grid = g_conv1_grid_cap;
 #ifndef MTN_EMU
     static MtnLdsAttr attr;
-    mtn_set_max_lds(attr, &conv1_fused_kernel<T, MODE>, lds);
+    mtn_set_max_lds(attr, &conv1_fused_kernel<T, MODE, S>, lds);
 #endif
-    MTN_LAUNCH((conv1_fused_kernel<T, MODE>), dim3(grid), dim3(PXB), lds, stream, x, (const T*)w, (T*)y, stats, B, H, W, OH, OW, ss, act);
+    MTN_LAUNCH((conv1_fused_kernel<T, MODE, S>), dim3(grid), dim3(PXB), lds, stream, x, (const T*)w, (S*)y, stats, B, H, W, OH, OW, ss, act);
     return mtn_check_launch("conv1_fused");
 }
 
@@ -536,8 +552,10 @@ template <int MODE>
 static int conv1_fused_launch(const float* x, const void* w, void* y, float* stats, const float* ss, int act, int dtype,
                               int B, int H, int W, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv1: bad geometry %dx%dx%d", B, H, W);
-    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32, "conv1: bad dtype %d", dtype);
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "conv1: bad dtype %d", dtype);
     MTN_REQUIRE((long)B * (H / 2) * (W / 2) * CO < (1L << 31), "conv1: tensor too large");
+    // split storage: the stem multiplies in exact f32 (its weights stay plain f32, optim.hip) and writes a split output
+    if (dtype == MTN_F32X3) return conv1_fused_launch_t<float, MODE, f32x3_t>(x, w, y, stats, ss, act, B, H, W, stream);
     return dtype == MTN_BF16 ? conv1_fused_launch_t<bf16_t, MODE>(x, w, y, stats, ss, act, B, H, W, stream)
                              : conv1_fused_launch_t<float, MODE>(x, w, y, stats, ss, act, B, H, W, stream);
 }
@@ -554,8 +572,7 @@ int mtn_conv1_bn_act_run(const float* x, const void* w, const float* scale_shift
     return conv1_fused_launch<2>(x, w, out, nullptr, scale_shift, act, dtype, B, H, W, stream);
 }
 
-static int g_conv1_x3 = 0;
-void mtn_conv1_set_x3(int v) { g_conv1_x3 = v ? 1 : 0; }
+void mtn_conv1_set_x3(int v) { (void)v; }     // (debug key 21 -- the stem backward on split-bf16 products -- retired in round 4)
 static int kBwdPx = 3072;           // pixels per workgroup of the fused backward (debug key 12): 768 workgroups = one round at B = 256
 void mtn_conv1_set_bwd_px(int n) { kBwdPx = n >= 64 ? (n / 64) * 64 : 3072; }
 int mtn_conv1_bwd_blocks(long M) { return (int)((M + kBwdPx - 1) / kBwdPx); }
@@ -571,15 +588,16 @@ int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const flo
     const int OH = H / 2, OW = W / 2;
     const long M = (long)B * OH * OW;
     const int blocks = mtn_conv1_bwd_blocks(M);
-#define MTN_CONV1_BWD(T, TR, SILU)                                                                                          \
-    MTN_LAUNCH((conv1_bwd_kernel<T, TR, SILU>), dim3(blocks), dim3(256), 0, stream, x, (const T*)w, (const T*)dout, scale_shift, \
+#define MTN_CONV1_BWD(T, TR, SILU, S)                                                                                       \
+    MTN_LAUNCH((conv1_bwd_kernel<T, TR, SILU, S>), dim3(blocks), dim3(256), 0, stream, x, (const T*)w, (const S*)dout, scale_shift, \
                mean_rstd, partial, B, H, W, OH, OW, kBwdPx)
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "conv1_bwd: bad dtype %d", dtype);
     if (dtype == MTN_BF16) {
-        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(bf16_t, true, true); else MTN_CONV1_BWD(bf16_t, true, false);
-    } else if (g_conv1_x3) {      // experiment (debug key 21): the fp32 stem backward on split-bf16 products
-        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(f32x3_t, false, true); else MTN_CONV1_BWD(f32x3_t, false, false);
+        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(bf16_t, true, true, bf16_t); else MTN_CONV1_BWD(bf16_t, true, false, bf16_t);
+    } else if (dtype == MTN_F32X3) {      // split storage: exact-f32 math on a split output gradient
+        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(float, false, true, f32x3_t); else MTN_CONV1_BWD(float, false, false, f32x3_t);
     } else {
-        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(float, false, true); else MTN_CONV1_BWD(float, false, false);
+        if (act == MTN_ACT_SILU) MTN_CONV1_BWD(float, false, true, float); else MTN_CONV1_BWD(float, false, false, float);
     }
 #undef MTN_CONV1_BWD
     int rc = mtn_check_launch("conv1_bwd");

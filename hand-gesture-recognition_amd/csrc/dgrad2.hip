@@ -39,7 +39,9 @@ void dgrad2_kernel(IgemmArgs p) {
     constexpr int KI = Mma<T>::KI, KS = BK / KI, NS = CS * KS;
     constexpr int FM = 2, FN = 2;
     constexpr int NQ = sizeof(T) == 2 ? 2 : 1;          // output-row parities staged per epilogue round
-    constexpr int CPR = NQ * 2 * BN / VEC;              // 16-byte chunks of one staged row ([qy][qx][n])
+    typedef typename StageT<T>::type CT;                // staged element (split storage stages f32 and splits on the way out)
+    constexpr int EV = Ev<T>::N;                        // channels per thread and access in the epilogue
+    constexpr int CPR = NQ * 2 * BN / EV;               // channel groups of one staged row ([qy][qx][n])
     constexpr int CP = NQ * 2 * BN + 16 / (int)sizeof(T);   // its pitch in elements
     static_assert(NT % CPR == 0, "store mapping");
 
@@ -50,7 +52,7 @@ void dgrad2_kernel(IgemmArgs p) {
     T* const sW = reinterpret_cast<T*>(smem);           // [2 stages][CS][BN][BK]
     T* const sWin = sW + 2 * CS * BN * BK;              // [CS][WR8][BK]
     const int zero_off = CS * WR8 * BK;                 // (relative to sWin) one zero row
-    T* const sC = reinterpret_cast<T*>(smem);           // [BM][CP] staged classes (after the K loop)
+    CT* const sC = reinterpret_cast<CT*>(smem);         // [BM][CP] staged classes (after the K loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 3, wn = wid >> 2;
@@ -169,22 +171,22 @@ void dgrad2_kernel(IgemmArgs p) {
     // (qy, qx, channel chunk) for all its rows.
     T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
     const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
-    const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
+    const int ccol = (tid % CPR) * EV, trow = tid / CPR;
     const int qyl = ccol / (2 * BN), qx = (ccol / BN) & 1, col = ccol % BN;
     constexpr int RPT = BM / (NT / CPR);
     // BatchNorm backward sums of the unit whose output gradient dx is (IgemmArgs::bn_y), as in igemm.hip
     const T* __restrict__ gBy = reinterpret_cast<const T*>(p.bn_y);
     const T* __restrict__ gBr = reinterpret_cast<const T*>(p.bn_res);
-    float st_s[VEC], st_q[VEC];
-    MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+    float st_s[EV], st_q[EV];
+    MTN_UNROLL for (int e = 0; e < EV; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
     MTN_UNROLL for (int r = 0; r < 2 / NQ; ++r) {
         if (r) __syncthreads();
         MTN_UNROLL for (int q = 0; q < NQ; ++q)
             MTN_UNROLL for (int x = 0; x < 2; ++x)
                 MTN_UNROLL for (int i = 0; i < FM; ++i)
                     MTN_UNROLL for (int j = 0; j < FN; ++j)
-                        store4<T>(sC + (wm * 32 + i * 16 + frow) * CP + (q * 2 + x) * BN + wn * 32 + j * 16 + 4 * (lane >> 4),
-                                  acc[(r * NQ + q) * 2 + x][i][j]);
+                        store4<CT>(sC + (wm * 32 + i * 16 + frow) * CP + (q * 2 + x) * BN + wn * 32 + j * 16 + 4 * (lane >> 4),
+                                   acc[(r * NQ + q) * 2 + x][i][j]);
         // (the accumulators of this round are dead now: room for the row prefetch)
         // this thread's rows: pixel (b, 2a + qy, 2c + qx) of each, -1 beyond Md
         const int qy = r * NQ + qyl;
@@ -195,18 +197,18 @@ void dgrad2_kernel(IgemmArgs p) {
             if (m < Md) decode(m, b, a, c);
             opix[i] = m < Md ? (b * p.OH + 2 * a + qy) * p.OW + 2 * c + qx : -1;
         }
-        // raw-output chunks of the BatchNorm unit: in flight across the barrier and the first rows
-        chunk16 bn_yv[RPT];
+        // raw-output values of the BatchNorm unit: in flight across the barrier and the first rows
+        RawVec<T> bn_yv[RPT];
         if (gBy) {
             MTN_UNROLL for (int i = 0; i < RPT; ++i) {
                 const long o = opix[i] < 0 ? 0 : opix[i];
-                bn_yv[i] = *reinterpret_cast<const chunk16*>(gBy + o * p.bn_ldy + n0 + col);
+                bn_yv[i] = ld_raw<T>(gBy + o * p.bn_ldy + n0, col);
             }
         }
         __syncthreads();
-        float bn_sc[VEC], bn_sh[VEC], bn_mu[VEC], bn_rs[VEC];
+        float bn_sc[EV], bn_sh[EV], bn_mu[EV], bn_rs[EV];
         if (gBy) {
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+            MTN_UNROLL for (int e = 0; e < EV; ++e) {
                 bn_sc[e] = p.bn_ss[n0 + col + e]; bn_sh[e] = p.bn_ss[p.N + n0 + col + e];
                 bn_mu[e] = p.bn_mr[n0 + col + e]; bn_rs[e] = p.bn_mr[p.N + n0 + col + e];
             }
@@ -215,22 +217,34 @@ void dgrad2_kernel(IgemmArgs p) {
             if (opix[i] < 0) continue;
             const int row = trow + i * (NT / CPR);
             const long o = opix[i];
-            chunk16 v = *reinterpret_cast<const chunk16*>(sC + row * CP + ccol);
-            if (gR) {
-                float f[VEC], rr[VEC];
-                unpack<T>(v, f);
-                unpack<T>(*reinterpret_cast<const chunk16*>(gR + o * p.ldr + n0 + col), rr);
-                MTN_UNROLL for (int e = 0; e < VEC; ++e) f[e] += rr[e];
-                v = pack<T>(f);
+            RawVec<T> v;
+            if constexpr (std::is_same<CT, T>::value) {           // staged in the storage type: the chunk leaves as it is
+                v.c = *reinterpret_cast<const chunk16*>(sC + row * CP + ccol);
+                if (gR) {
+                    float f[EV], rr[EV];
+                    unpack<T>(v.c, f);
+                    ld_vec<T>(gR + o * p.ldr + n0, col, rr);
+                    MTN_UNROLL for (int e = 0; e < EV; ++e) f[e] += rr[e];
+                    v = pack_raw<T>(f);
+                }
+            } else {                                              // split storage: f32 staging, split on the way out
+                float f[EV];
+                MTN_UNROLL for (int e = 0; e < EV; ++e) f[e] = sC[row * CP + ccol + e];
+                if (gR) {
+                    float rr[EV];
+                    ld_vec<T>(gR + o * p.ldr + n0, col, rr);
+                    MTN_UNROLL for (int e = 0; e < EV; ++e) f[e] += rr[e];
+                }
+                v = pack_raw<T>(f);
             }
-            *reinterpret_cast<chunk16*>(gO + o * p.ldc + n0 + col) = v;
+            st_raw<T>(gO + o * p.ldc + n0, col, v);
             if (gBy) {
-                float w[VEC], yv[VEC], rr[VEC], dz[VEC], xh[VEC];
-                unpack<T>(v, w);
-                unpack<T>(bn_yv[i], yv);
-                if (gBr) unpack<T>(*reinterpret_cast<const chunk16*>(gBr + o * p.bn_ldr + n0 + col), rr);
-                bn_dz_math<VEC>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
-                MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
+                float w[EV], yv[EV], rr[EV], dz[EV], xh[EV];
+                unpack_raw<T>(v, w);
+                unpack_raw<T>(bn_yv[i], yv);
+                if (gBr) ld_vec<T>(gBr + o * p.bn_ldr + n0, col, rr);
+                bn_dz_math<EV>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
+                MTN_UNROLL for (int e = 0; e < EV; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
             }
         }
     }
@@ -238,7 +252,7 @@ void dgrad2_kernel(IgemmArgs p) {
         constexpr int TRN = NT / CPR, RW = NQ * 2 * BN;
         __syncthreads();                                   // everyone is done reading the staged tile
         float* red = reinterpret_cast<float*>(smem);       // [2][TRN][RW]
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+        MTN_UNROLL for (int e = 0; e < EV; ++e) {
             red[trow * RW + ccol + e] = st_s[e];
             red[(TRN + trow) * RW + ccol + e] = st_q[e];
         }

@@ -70,12 +70,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
 // lets its scheduler spend registers on keeping the fragment reads of a K step in flight instead
 // of minimising pressure for an occupancy the LDS footprint rules out anyway.
 #ifdef MTN_EMU
-#define MTN_WAVES_PER_SIMD(n)
+#define MTN_WAVES_PER_SIMD(lo, hi)
 #else
-#define MTN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(1, n)))
+#define MTN_WAVES_PER_SIMD(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
+// (4-byte storage: a split-storage fragment is 8 registers, and left to itself hipcc spends 130-137 / 176 registers on the
+//  8-wave 128x128 / the 4-wave tiles -- one over the step that keeps two / three workgroups per CU resident; the lower bound
+//  holds it to 128 / 168)
+template <class T, int BM, int BN, int NT> struct IgemmOcc {
+    static constexpr bool big = BM * BN >= 128 * 128;
+    static constexpr int lo = sizeof(T) == 4 ? (big ? (NT == 512 ? 4 : 1) : 3) : 1;
+    static constexpr int hi = big ? (sizeof(T) == 4 && NT == 512 ? 4 : 2) : 3;
+};
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
-__global__ __launch_bounds__(WGM* WGN * 64) MTN_WAVES_PER_SIMD((BM * BN >= 128 * 128 ? 2 : 3))
+__global__ __launch_bounds__(WGM* WGN * 64) MTN_WAVES_PER_SIMD((IgemmOcc<T, BM, BN, WGM * WGN * 64>::lo), (IgemmOcc<T, BM, BN, WGM * WGN * 64>::hi))
 void igemm_kernel(IgemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int BK = ROW_BYTES / (int)sizeof(T);
@@ -87,7 +95,8 @@ void igemm_kernel(IgemmArgs p) {
     constexpr int RA = BM * 8 / NT;      // A chunks per thread per K step
     constexpr int RB = BN * 8 / NT;      // W chunks per thread per K step
     constexpr int RSTEP = NT / 8;        // rows between a thread's chunks
-    typedef typename std::conditional<STAGES != 2, T, float>::type CT;     // staged C element
+    typedef typename std::conditional<STAGES != 2, typename StageT<T>::type, float>::type CT;     // staged C element
+    constexpr int EV = Ev<T>::N;         // channels per thread in the epilogue (split storage: a hi and a lo chunk of 8)
     constexpr bool DMA = STAGES >= 3;
     constexpr bool WIN = STAGES == 5 || STAGES == 6;
     constexpr bool IMG = STAGES == 6;      // window mode, whole reduction axis resident, weights through registers
@@ -311,28 +320,8 @@ void igemm_kernel(IgemmArgs p) {
     auto store_tiles = [&](int stage) {
         T* a = sA + stage * BM * PITCH;
         T* b = sB + stage * BN * PITCH;
-        if constexpr (X3) {
-            // split-on-store: the 144-byte row holds [32 hi bf16][32 lo bf16][pad]; this thread's 4 values land at
-            // byte 8 * chunk of either half (mtn_types.h: Split4)
-            auto put = [&](T* rowp, const chunk16& c) {
-                const Split4 s = split_pack4(c);
-                // chunk c = k 4c..4c+3 -> slot (c & 3), first / second half of the slot (x3_block_pos)
-                char* q = reinterpret_cast<char*>(rowp) + (chunk & 3) * 16 + (chunk >> 2) * 8;
-#ifdef MTN_EMU
-                std::memcpy(q, s.hi, 8); std::memcpy(q + 64, s.lo, 8);
-#else
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 h, l;
-                h[0] = s.hi[0]; h[1] = s.hi[1]; l[0] = s.lo[0]; l[1] = s.lo[1];
-                *reinterpret_cast<u32x2*>(q) = h;
-                *reinterpret_cast<u32x2*>(q + 64) = l;
-#endif
-            };
-            MTN_UNROLL for (int i = 0; i < RA; ++i) put(a + (row0 + i * RSTEP) * PITCH, ra[i]);
-            MTN_UNROLL for (int i = 0; i < RB; ++i)          // the weights arrive pre-split: the same bytes, copied
-                *reinterpret_cast<chunk16*>(b + (row0 + i * RSTEP) * PITCH + chunk * VEC) = rb[i];
-            return;
-        }
+        // (split storage: the 128 bytes of a K step are one block [32 hi][32 lo] as they come from memory -- copied like any
+        //  other row; `compute` reads the hi fragment at 16 * g and the lo fragment 64 bytes further)
         MTN_UNROLL for (int i = 0; i < RA; ++i)
             *reinterpret_cast<chunk16*>(a + (row0 + i * RSTEP) * PITCH + chunk * VEC) = ra[i];
         MTN_UNROLL for (int i = 0; i < RB; ++i)
@@ -440,7 +429,7 @@ void igemm_kernel(IgemmArgs p) {
             return;
         }
         if constexpr (X3) {
-            // tiles written split-on-store: fragments are plain bf16x8 reads of the hi and the lo half of a row
+            // split storage: fragments are plain bf16x8 reads of the hi and the lo half of a row
             const char* a = reinterpret_cast<const char*>(sA + stage * BM * PITCH + (wm * WM + frow) * PITCH) + 16 * fg;
             const char* b = reinterpret_cast<const char*>(sB + stage * BN * PITCH + (wn * WN + frow) * PITCH) + 16 * fg;
             Frag3 fa[FM], fb[FN];
@@ -685,11 +674,11 @@ void igemm_kernel(IgemmArgs p) {
     T* __restrict__ gO = reinterpret_cast<T*>(p.Out);
     T* __restrict__ gAux = reinterpret_cast<T*>(p.aux_out);
     const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
-    constexpr int CPR = BN / VEC;     // chunks per row
-    constexpr int TR = NT / CPR;      // thread rows: a thread keeps ONE column chunk for all its rows
+    constexpr int CPR = BN / EV;      // channel groups per row
+    constexpr int TR = NT / CPR;      // thread rows: a thread keeps ONE column group for all its rows
     constexpr int RPT = BM / TR;      // rows per thread
     static_assert(NT % CPR == 0 && BM % TR == 0, "store mapping");
-    const int ccol = (tid % CPR) * VEC, trow = tid / CPR;
+    const int ccol = (tid % CPR) * EV, trow = tid / CPR;
     // output row of each of this thread's rows (-1: beyond M)
     int orow[RPT];
     MTN_UNROLL for (int i = 0; i < RPT; ++i) {
@@ -703,20 +692,20 @@ void igemm_kernel(IgemmArgs p) {
         orow[i] = m;
     }
     // Data gradient feeding a BatchNorm unit's backward (IgemmArgs::bn_y): that unit's per-channel constants
-    // for this thread's chunk, and its raw-output chunks of this thread's rows -- requested HERE,
+    // for this thread's channels, and its raw-output values of this thread's rows -- requested HERE,
     // before the accumulators are staged, so their latency hides behind the staging and its barrier.
     const T* __restrict__ gBy = reinterpret_cast<const T*>(p.bn_y);
     const T* __restrict__ gBr = reinterpret_cast<const T*>(p.bn_res);
-    float bn_sc[VEC], bn_sh[VEC], bn_mu[VEC], bn_rs[VEC];
-    chunk16 bn_yv[RPT];
+    float bn_sc[EV], bn_sh[EV], bn_mu[EV], bn_rs[EV];
+    RawVec<T> bn_yv[RPT];
     if (gBy) {
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+        MTN_UNROLL for (int e = 0; e < EV; ++e) {
             bn_sc[e] = p.bn_ss[n0 + ccol + e]; bn_sh[e] = p.bn_ss[p.N + n0 + ccol + e];
             bn_mu[e] = p.bn_mr[n0 + ccol + e]; bn_rs[e] = p.bn_mr[p.N + n0 + ccol + e];
         }
         MTN_UNROLL for (int i = 0; i < RPT; ++i) {
             const long m = orow[i] < 0 ? 0 : orow[i];
-            bn_yv[i] = *reinterpret_cast<const chunk16*>(gBy + m * p.bn_ldy + n0 + ccol);
+            bn_yv[i] = ld_raw<T>(gBy + m * p.bn_ldy + n0, ccol);
         }
     }
     // The MFMAs take the W fragment as their row operand, so a lane's four accumulator registers
@@ -728,46 +717,46 @@ void igemm_kernel(IgemmArgs p) {
     __syncthreads();
     STAMP(st_e1);
 
-    float st_s[VEC], st_q[VEC];
-    MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+    float st_s[EV], st_q[EV];
+    MTN_UNROLL for (int e = 0; e < EV; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
     MTN_UNROLL for (int i = 0; i < RPT; ++i) {
         const int row = trow + i * TR;
         const int m = orow[i];
         if (m < 0) continue;
-        float v[VEC];
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = to_f<CT>(sC[row * CP + ccol + e]);
+        float v[EV];
+        MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] = to_f<CT>(sC[row * CP + ccol + e]);
         if (p.bias) {
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += p.bias[n0 + ccol + e];
+            MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] += p.bias[n0 + ccol + e];
         }
         if (p.act == MTN_ACT_GELU) {
-            if (gAux) *reinterpret_cast<chunk16*>(gAux + (long)m * p.ld_aux + n0 + ccol) = pack<T>(v);
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = geluf_(v[e]);
+            if (gAux) st_vec<T>(gAux + (long)m * p.ld_aux + n0, ccol, v);
+            MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] = geluf_(v[e]);
         } else if (MODE == 4) {                        // GELU backward on a data gradient: aux holds the saved pre-activation
-            float av[VEC];
-            unpack<T>(*reinterpret_cast<const chunk16*>(gAux + (long)m * p.ld_aux + n0 + ccol), av);
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] *= gelu_grad_(av[e]);
+            float av[EV];
+            ld_vec<T>(gAux + (long)m * p.ld_aux + n0, ccol, av);
+            MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] *= gelu_grad_(av[e]);
         }
         if (gR) {
-            float rr[VEC];
-            unpack<T>(*reinterpret_cast<const chunk16*>(gR + (long)m * p.ldr + n0 + ccol), rr);
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] += rr[e];
+            float rr[EV];
+            ld_vec<T>(gR + (long)m * p.ldr + n0, ccol, rr);
+            MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] += rr[e];
         }
         if (p.act == MTN_ACT_SILU) {                   // inference with folded BatchNorm: SiLU(conv + shift [+ res])
-            MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = siluf_(v[e]);
+            MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] = siluf_(v[e]);
         }
-        const chunk16 o = pack<T>(v);
-        *reinterpret_cast<chunk16*>(gO + (long)m * p.ldc + n0 + ccol) = o;
+        const RawVec<T> o = pack_raw<T>(v);
+        st_raw<T>(gO + (long)m * p.ldc + n0, ccol, o);
         if (p.stats) {          // statistics of the values exactly as stored
-            float w[VEC];
-            unpack<T>(o, w);
+            float w[EV];
+            unpack_raw<T>(o, w);
             if (gBy) {          // sum dz, sum dz*xhat of the BatchNorm unit whose output gradient this row is
-                float yv[VEC], rr[VEC], dz[VEC], xh[VEC];
-                unpack<T>(bn_yv[i], yv);
-                if (gBr) unpack<T>(*reinterpret_cast<const chunk16*>(gBr + (long)m * p.bn_ldr + n0 + ccol), rr);
-                bn_dz_math<VEC>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
-                MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
+                float yv[EV], rr[EV], dz[EV], xh[EV];
+                unpack_raw<T>(bn_yv[i], yv);
+                if (gBr) ld_vec<T>(gBr + (long)m * p.bn_ldr + n0, ccol, rr);
+                bn_dz_math<EV>(w, yv, rr, gBr != nullptr, bn_sc, bn_sh, bn_mu, bn_rs, p.bn_act == MTN_ACT_SILU, dz, xh);
+                MTN_UNROLL for (int e = 0; e < EV; ++e) { st_s[e] += dz[e]; st_q[e] += dz[e] * xh[e]; }
             } else {
-                MTN_UNROLL for (int e = 0; e < VEC; ++e) { st_s[e] += w[e]; st_q[e] += w[e] * w[e]; }
+                MTN_UNROLL for (int e = 0; e < EV; ++e) { st_s[e] += w[e]; st_q[e] += w[e] * w[e]; }
             }
         }
     }
@@ -775,7 +764,7 @@ void igemm_kernel(IgemmArgs p) {
     if (p.stats) {
         __syncthreads();                                   // everyone is done reading the C tile
         float* red = reinterpret_cast<float*>(smem);       // [2][TR][BN]
-        MTN_UNROLL for (int e = 0; e < VEC; ++e) {
+        MTN_UNROLL for (int e = 0; e < EV; ++e) {
             red[trow * BN + ccol + e] = st_s[e];
             red[(TR + trow) * BN + ccol + e] = st_q[e];
         }
@@ -852,7 +841,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     constexpr size_t lds_ab = STAGES == 8 ? 2 * (size_t)BM * ROW_BYTES : STAGES >= 3 ? (STAGES == 7 ? 3 : STAGES - 1) * (size_t)(BM + BN) * ROW_BYTES : STAGES * (size_t)(BM + BN) * PITCH_BYTES;
     constexpr size_t csz = STAGES != 2 ? sizeof(T) : 4;
     constexpr size_t lds_c = (size_t)BM * (BN * csz + 16);
-    constexpr size_t lds_r = (size_t)NT * (16 / sizeof(T)) * 2 * 4;    // stats reduction scratch [2][TR][BN]
+    constexpr size_t lds_r = (size_t)NT * Ev<T>::N * 2 * 4;    // stats reduction scratch [2][TR][BN], TR = NT / (BN / Ev<T>::N)
     constexpr size_t lds0 = lds_ab > lds_c ? lds_ab : lds_c;
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
     int win_cs = 0;
@@ -1041,6 +1030,13 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     MTN_REQUIRE((long)p.B * p.H * p.W * p.lda < (1L << 30) && (long)p.M * p.ldc < (1L << 31) && (long)p.N * p.K < (1L << 30),
                 "igemm: tensor too large for 32-bit byte offsets");
     MTN_REQUIRE(((uintptr_t)p.A | (uintptr_t)p.Wp | (uintptr_t)p.Out | (uintptr_t)p.res | (uintptr_t)p.aux_out) % 16 == 0, "igemm: pointers must be 16-byte aligned");
+    // split storage: rows are sequences of whole 32-channel blocks [32 hi][32 lo] -- every operand starts on one and
+    // every row pitch is a whole number of them
+    MTN_REQUIRE(dtype != MTN_F32X3 ||
+                    (((uintptr_t)p.A | (uintptr_t)p.Wp | (uintptr_t)p.Out | (uintptr_t)p.res | (uintptr_t)p.aux_out | (uintptr_t)p.bn_y | (uintptr_t)p.bn_res) % 16 == 0 &&
+                     p.lda % 32 == 0 && p.ldc % 32 == 0 && (!p.res || p.ldr % 32 == 0) && (!p.aux_out || p.ld_aux % 32 == 0) &&
+                     (!p.bn_y || p.bn_ldy % 32 == 0) && (!p.bn_res || p.bn_ldr % 32 == 0)),
+                "igemm: split storage (MTN_DTYPE_F32X3) needs 16-byte aligned operands and row pitches that are multiples of 32");
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
     if (dtype == MTN_F32X3) return dispatch_igemm<f32x3_t>(p, stream);
     return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);

@@ -6,7 +6,8 @@
 #define MTN_F32 MTN_DTYPE_F32
 #define MTN_BF16 MTN_DTYPE_BF16
 #define MTN_F32X3 MTN_DTYPE_F32X3
-// storage type behind a dtype code: everything that is not a GEMM-shaped kernel sees F32X3 as plain F32
+// the kernels that have no split-storage form (the stem's unfused ABI entries, the pose head) take PLAIN f32 operands
+// when they are called with MTN_DTYPE_F32X3: the caller converts at that boundary (mtn_x3_convert)
 static inline int mtn_storage_dtype(int dtype) { return dtype == MTN_DTYPE_F32X3 ? MTN_DTYPE_F32 : dtype; }
 #define MTN_ACT_GELU_GRAD_ 100     // igemm epilogue only: multiply by gelu'(saved pre-activation)
 
@@ -131,6 +132,7 @@ struct AttnArgs {
 int mtn_attn_fwd_run(const AttnArgs& a, int dtype, hipStream_t stream);
 int mtn_attn_bwd_run(const AttnArgs& a, int dtype, hipStream_t stream);
 
+int mtn_x3_convert_run(const void* src, int ld_src, void* dst, int ld_dst, int to_split, long M, int C, hipStream_t stream);
 int mtn_tokens_fwd_run(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B, int P, hipStream_t stream);
 int mtn_tokens_bwd_run(const void* dtok, void* dfeat, float* dcls, int dtype, int B, int P, hipStream_t stream);
 int mtn_ln_fwd_run(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean_rstd, int dtype,

@@ -4,11 +4,15 @@
 //   bf16_t : throughput mode -- bf16 activations/weights, MFMA bf16, fp32 accumulate
 //   float  : validation mode -- fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32),
 //            the mode the 1e-3 parity gate against the fp32 reference is run in.
-//   f32x3_t: fp32 storage like `float` (every elementwise / reduction kernel runs its float
-//            instantiation on it unchanged); the GEMM-shaped kernels (igemm / dgrad2 / wgrad) split each
-//            operand into bf16 hi + bf16 lo IN REGISTERS after the LDS read and multiply with three
-//            bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-17 relative
-//            error per product at 3/16 of the exact-f32 MFMA time -- the 1e-3 gate at throughput.
+//   f32x3_t: SPLIT storage, 4 bytes per element like `float`: every 32-channel block of a row (128 bytes) holds
+//            [32 bf16 hi][32 bf16 lo] with hi = bf16_rne(x), lo = bf16_rne(x - hi), channels in natural order.
+//            The PRODUCER of a tensor splits each element once (st_vec / st4 below); the GEMM-shaped kernels
+//            (igemm / dgrad2 / wgrad / attention) read their MFMA fragments as plain bf16 -- two 16-byte rows
+//            reads or ds_read_b64_tr_b16 column reads, no conversion -- and multiply with three bf16 MFMAs per
+//            product (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-17 relative error per product at 3/16 of
+//            the exact-f32 MFMA time; elementwise consumers rebuild x = hi + lo (one add).  Until round 4
+//            the mode kept plain fp32 in memory and split every fragment in registers, per wave, tile and
+//            tap (24 VALU per fragment: DESIGN.md section 7e).
 #pragma once
 #include "mtn_rt.h"
 
@@ -43,13 +47,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // v_cvt_pk_bf16_f32: RNE, k
 template <class T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
-template <> __device__ __forceinline__ float to_f<f32x3_t>(f32x3_t x) { return x.v; }
 template <class T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
-template <> __device__ __forceinline__ f32x3_t from_f<f32x3_t>(float x) { f32x3_t r; r.v = x; return r; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
+// (f32x3_t -- split storage -- has no per-element to_f / from_f: its accessors are ld_vec / st_vec / ld4 / st4 / ld1 below)
 // value as it will read back from storage of type T
 template <class T> __device__ __forceinline__ float round_to(float x) { return to_f<T>(from_f<T>(x)); }
+template <> __device__ __forceinline__ float round_to<f32x3_t>(float x);
 
 // 16-byte chunk: the unit of every global<->LDS move (8 bf16 or 4 f32)
 #ifdef MTN_EMU
@@ -77,7 +81,6 @@ template <> __device__ __forceinline__ void unpack<bf16_t>(const chunk16& c, flo
         f[2 * i] = bf2f(lo); f[2 * i + 1] = bf2f(hi);
     }
 }
-template <> __device__ __forceinline__ void unpack<f32x3_t>(const chunk16& c, float* f) { unpack<float>(c, f); }
 template <class T> __device__ __forceinline__ chunk16 pack(const float* f);
 template <> __device__ __forceinline__ chunk16 pack<float>(const float* f) {
     chunk16 c;
@@ -94,7 +97,6 @@ template <> __device__ __forceinline__ chunk16 pack<bf16_t>(const float* f) {
         c[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
     return c;
 }
-template <> __device__ __forceinline__ chunk16 pack<f32x3_t>(const float* f) { return pack<float>(f); }
 // four consecutive elements from one accumulator quad (dst 8- / 16-byte aligned)
 template <class T> __device__ __forceinline__ void store4(T* dst, const f32x4_t& v);
 template <> __device__ __forceinline__ void store4<float>(float* dst, const f32x4_t& v) {
@@ -114,9 +116,6 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const f3
     o[1] = (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16);
     *reinterpret_cast<u32x2_t*>(dst) = o;
 #endif
-}
-template <> __device__ __forceinline__ void store4<f32x3_t>(f32x3_t* dst, const f32x4_t& v) {
-    store4<float>(reinterpret_cast<float*>(dst), v);
 }
 __device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c[0] = 0u; c[1] = 0u; c[2] = 0u; c[3] = 0u; return c; }
 
@@ -164,30 +163,21 @@ template <> struct Mma<float> {
     }
 };
 
-// fp32 storage, split-bf16 multiply.  One "instruction" = three 16x16x32 bf16 MFMAs over 32 k: lane
-// group g = lane >> 4 holds EIGHT fp32 k-values of its row, split in registers into
+// Split storage, split-bf16 multiply.  One "instruction" = three 16x16x32 bf16 MFMAs over 32 k: lane group
+// g = lane >> 4 holds the hi and the lo halves of EIGHT k-values of its row,
 //   hi = bf16_rne(x),  lo = bf16_rne(x - hi)        (x - hi is exact in fp32)
-// and the product is hi*hi + hi*lo + lo*hi (lo*lo ~ 2^-18 |ab| is dropped).  WHICH eight k-values a
-// lane group holds is free as long as both operands use the same assignment (an MFMA sums over k):
-// the row-major LDS tiles of igemm / dgrad2 give group g the 16-byte slots g and g + 4 of the 128-byte
-// row (RowFrag below: conflict-free under the XOR swizzle, where two adjacent slots are 2-way
-// conflicted), the pixel-major tiles of wgrad give it rows g, g + 4, ..., g + 28.
+// and the product is hi*hi + hi*lo + lo*hi (lo*lo ~ 2^-18 |ab| is dropped).  WHICH eight k-values a lane group
+// holds is free as long as both operands use the same assignment (an MFMA sums over k): the row-major LDS
+// tiles of igemm / dgrad2 / attention give group g the channels 8g .. 8g+7 of the 32-channel block (RowFrag
+// below), the pixel-major tiles of wgrad the pixels 8g .. 8g+7 of the step (ds_read_b64_tr_b16 down the hi and
+// the lo columns).  Both halves come out of memory as stored; `split` serves values that are COMPUTED in
+// registers (the attention probabilities).
 struct Frag3 { bf16x8_t hi, lo; };
 template <> struct Mma<f32x3_t> {
     static constexpr int KI = 32;
     typedef Frag3 Frag;
     static __device__ __forceinline__ Frag split(const float* x) {       // 8 values
         Frag f;
-#if defined(MTN_X3_FAKE) && !defined(MTN_EMU)
-        // timing-only diagnostic build (wrong numerics): the fragment is the raw bits, no conversion -- the upper bound
-        // of what storing the operands pre-split can gain
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 a, b;
-        MTN_UNROLL for (int j = 0; j < 4; ++j) { a[j] = __float_as_uint(x[j]); b[j] = __float_as_uint(x[4 + j]); }
-        f.hi = __builtin_bit_cast(bf16x8_t, a);
-        f.lo = __builtin_bit_cast(bf16x8_t, b);
-        return f;
-#endif
 #ifdef MTN_EMU
         MTN_UNROLL for (int j = 0; j < 8; ++j) {
             const bf16_t h = f2bf(x[j]);
@@ -209,10 +199,16 @@ template <> struct Mma<f32x3_t> {
         unpack<float>(c1, x + 4);
         return split(x);
     }
-    // 8 consecutive k-values at p (16-byte aligned)
+    // lane group g of an UNSWIZZLED split row: p = row + 4 g (the 16-byte hi slot of k = 8g .. 8g+7), lo 64 bytes further
     static __device__ __forceinline__ Frag load(const f32x3_t* p) {
-        const chunk16* q = reinterpret_cast<const chunk16*>(p);
-        return split2(q[0], q[1]);
+        Frag f;
+#ifdef MTN_EMU
+        std::memcpy(&f.hi, p, 16); std::memcpy(&f.lo, p + 16, 16);
+#else
+        f.hi = *reinterpret_cast<const bf16x8_t*>(p);
+        f.lo = *reinterpret_cast<const bf16x8_t*>(p + 16);
+#endif
+        return f;
     }
     static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
 #ifdef MTN_EMU
@@ -227,30 +223,130 @@ template <> struct Mma<f32x3_t> {
     }
 };
 
-// Split-on-store form (register-staged pipelines): four fp32 values -> 4 bf16 hi (8 bytes) + 4 bf16 lo (8 bytes).  A tile
-// written this way holds a row as [32 hi][32 lo] bf16 and its fragments are plain 16-byte bf16x8 reads: every element is
-// converted ONCE on its way into LDS instead of once per wave that reads it (24 VALU per fragment and wave otherwise).
-struct Split4 { unsigned hi[2], lo[2]; };
-__device__ __forceinline__ Split4 split_pack4(const chunk16& c) {
-    float x[4];
-    unpack<float>(c, x);
-    unsigned short h[4], l[4];
-    MTN_UNROLL for (int j = 0; j < 4; ++j) {
-        const bf16_t hb = f2bf(x[j]);
-        h[j] = hb.v;
-        l[j] = f2bf(x[j] - bf2f(hb)).v;
-    }
-    Split4 s;
-    s.hi[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); s.hi[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
-    s.lo[0] = (unsigned)l[0] | ((unsigned)l[1] << 16); s.lo[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
-    return s;
-}
 __device__ __forceinline__ bf16x8_t load_bf16x8(const void* p) {
 #ifdef MTN_EMU
     bf16x8_t f; std::memcpy(&f, p, 16); return f;
 #else
     return *reinterpret_cast<const bf16x8_t*>(p);
 #endif
+}
+
+// ---- channel access to stored tensors --------------------------------------------------------------
+// Ev<T>::N = channels one thread moves per access of an elementwise pass / epilogue: one 16-byte chunk for bf16 (8) and
+// float (4); for split storage the 16-byte hi chunk and the 16-byte lo chunk (64 bytes further) of 8 channels.
+// `row` is a pointer to channel 0 of a row -- or to any channel that is a multiple of 32 (slices of the concat buffers
+// start at multiples of 64) -- and c a multiple of Ev<T>::N; pointer arithmetic in units of T stays valid for whole
+// 32-channel blocks because a block is 32 x 4 bytes either way.
+template <class T> struct Ev { static constexpr int N = 16 / (int)sizeof(T); };
+template <> struct Ev<f32x3_t> { static constexpr int N = 8; };
+// staging type of an accumulator tile in LDS (split storage stages plain f32 and splits on the way out)
+template <class T> struct StageT { typedef T type; };
+template <> struct StageT<f32x3_t> { typedef float type; };
+
+// bf16 index of channel c's hi half inside a split row (lo: + 32)
+__device__ __forceinline__ int x3_pos(int c) { return ((c & ~31) << 1) + (c & 31); }
+
+__device__ __forceinline__ void x3_split8(const float* v, chunk16& h, chunk16& l) {
+    MTN_UNROLL for (int i = 0; i < 4; ++i) {
+        const bf16_t h0 = f2bf(v[2 * i]), h1 = f2bf(v[2 * i + 1]);
+        const bf16_t l0 = f2bf(v[2 * i] - bf2f(h0)), l1 = f2bf(v[2 * i + 1] - bf2f(h1));
+        h[i] = (unsigned)h0.v | ((unsigned)h1.v << 16);
+        l[i] = (unsigned)l0.v | ((unsigned)l1.v << 16);
+    }
+}
+__device__ __forceinline__ float bits_f(unsigned u) {
+#ifdef MTN_EMU
+    float f; std::memcpy(&f, &u, 4); return f;
+#else
+    return __uint_as_float(u);
+#endif
+}
+__device__ __forceinline__ void x3_join8(const chunk16& h, const chunk16& l, float* v) {
+    MTN_UNROLL for (int i = 0; i < 4; ++i) {
+        v[2 * i] = bits_f(h[i] << 16) + bits_f(l[i] << 16);
+        v[2 * i + 1] = bits_f(h[i] & 0xffff0000u) + bits_f(l[i] & 0xffff0000u);
+    }
+}
+
+// raw bits of Ev<T>::N channels (a load that is issued early and unpacked later keeps this, not floats)
+template <class T> struct RawVec { chunk16 c; };
+template <> struct RawVec<f32x3_t> { chunk16 h, l; };
+template <class T> __device__ __forceinline__ RawVec<T> ld_raw(const T* row, int c) {
+    RawVec<T> r; r.c = *reinterpret_cast<const chunk16*>(row + c); return r;
+}
+template <> __device__ __forceinline__ RawVec<f32x3_t> ld_raw<f32x3_t>(const f32x3_t* row, int c) {
+    const bf16_t* q = reinterpret_cast<const bf16_t*>(row) + x3_pos(c);
+    RawVec<f32x3_t> r;
+    r.h = *reinterpret_cast<const chunk16*>(q);
+    r.l = *reinterpret_cast<const chunk16*>(q + 32);
+    return r;
+}
+template <class T> __device__ __forceinline__ void st_raw(T* row, int c, const RawVec<T>& r) {
+    *reinterpret_cast<chunk16*>(row + c) = r.c;
+}
+template <> __device__ __forceinline__ void st_raw<f32x3_t>(f32x3_t* row, int c, const RawVec<f32x3_t>& r) {
+    bf16_t* q = reinterpret_cast<bf16_t*>(row) + x3_pos(c);
+    *reinterpret_cast<chunk16*>(q) = r.h;
+    *reinterpret_cast<chunk16*>(q + 32) = r.l;
+}
+template <class T> __device__ __forceinline__ void unpack_raw(const RawVec<T>& r, float* v) { unpack<T>(r.c, v); }
+template <> __device__ __forceinline__ void unpack_raw<f32x3_t>(const RawVec<f32x3_t>& r, float* v) { x3_join8(r.h, r.l, v); }
+template <class T> __device__ __forceinline__ RawVec<T> pack_raw(const float* v) { RawVec<T> r; r.c = pack<T>(v); return r; }
+template <> __device__ __forceinline__ RawVec<f32x3_t> pack_raw<f32x3_t>(const float* v) {
+    RawVec<f32x3_t> r; x3_split8(v, r.h, r.l); return r;
+}
+template <class T> __device__ __forceinline__ RawVec<T> zero_raw() { RawVec<T> r; r.c = zero_chunk(); return r; }
+template <> __device__ __forceinline__ RawVec<f32x3_t> zero_raw<f32x3_t>() { RawVec<f32x3_t> r; r.h = zero_chunk(); r.l = zero_chunk(); return r; }
+template <class T> __device__ __forceinline__ void ld_vec(const T* row, int c, float* v) { unpack_raw<T>(ld_raw<T>(row, c), v); }
+template <class T> __device__ __forceinline__ void st_vec(T* row, int c, const float* v) { st_raw<T>(row, c, pack_raw<T>(v)); }
+
+// four consecutive channels c .. c+3 (c % 4 == 0) of a row: the row-wise ViT kernels (one wave per 256-wide row) and
+// the attention epilogues (an accumulator quad)
+template <class T> __device__ __forceinline__ void ld4(const T* row, int c, float* v);
+template <> __device__ __forceinline__ void ld4<float>(const float* row, int c, float* v) {
+    unpack<float>(*reinterpret_cast<const chunk16*>(row + c), v);
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* row, int c, float* v) {
+    const unsigned* q = reinterpret_cast<const unsigned*>(row + c);
+    const unsigned a = q[0], b = q[1];
+    v[0] = bits_f(a << 16); v[1] = bits_f(a & 0xffff0000u); v[2] = bits_f(b << 16); v[3] = bits_f(b & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ld4<f32x3_t>(const f32x3_t* row, int c, float* v) {
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(row) + x3_pos(c);
+    const unsigned* q = reinterpret_cast<const unsigned*>(p);
+    const unsigned* ql = reinterpret_cast<const unsigned*>(p + 32);
+    const unsigned a = q[0], b = q[1], la = ql[0], lb = ql[1];
+    v[0] = bits_f(a << 16) + bits_f(la << 16); v[1] = bits_f(a & 0xffff0000u) + bits_f(la & 0xffff0000u);
+    v[2] = bits_f(b << 16) + bits_f(lb << 16); v[3] = bits_f(b & 0xffff0000u) + bits_f(lb & 0xffff0000u);
+}
+template <class T> __device__ __forceinline__ void st4(T* row, int c, const float* v);
+template <> __device__ __forceinline__ void st4<float>(float* row, int c, const float* v) {
+    *reinterpret_cast<chunk16*>(row + c) = pack<float>(v);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* row, int c, const float* v) {
+    unsigned* q = reinterpret_cast<unsigned*>(row + c);
+    q[0] = (unsigned)f2bf(v[0]).v | ((unsigned)f2bf(v[1]).v << 16);
+    q[1] = (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16);
+}
+template <> __device__ __forceinline__ void st4<f32x3_t>(f32x3_t* row, int c, const float* v) {
+    bf16_t* p = reinterpret_cast<bf16_t*>(row) + x3_pos(c);
+    unsigned* q = reinterpret_cast<unsigned*>(p);
+    unsigned* ql = reinterpret_cast<unsigned*>(p + 32);
+    bf16_t h[4], l[4];
+    MTN_UNROLL for (int e = 0; e < 4; ++e) { h[e] = f2bf(v[e]); l[e] = f2bf(v[e] - bf2f(h[e])); }
+    q[0] = (unsigned)h[0].v | ((unsigned)h[1].v << 16); q[1] = (unsigned)h[2].v | ((unsigned)h[3].v << 16);
+    ql[0] = (unsigned)l[0].v | ((unsigned)l[1].v << 16); ql[1] = (unsigned)l[2].v | ((unsigned)l[3].v << 16);
+}
+// one channel (reductions that walk a column)
+template <class T> __device__ __forceinline__ float ld1(const T* row, int c) { return to_f<T>(row[c]); }
+template <> __device__ __forceinline__ float ld1<f32x3_t>(const f32x3_t* row, int c) {
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(row) + x3_pos(c);
+    return bf2f(p[0]) + bf2f(p[32]);
+}
+// value as it will read back from storage of type T (statistics are taken of what the consumers will see)
+template <> __device__ __forceinline__ float round_to<f32x3_t>(float x) {
+    const bf16_t h = f2bf(x);
+    return bf2f(h) + bf2f(f2bf(x - bf2f(h)));
 }
 
 // Operand fragment of K-sub-step ks from a ROW of an XOR-swizzled row-major LDS tile (128-byte rows of
@@ -262,33 +358,21 @@ template <class T> struct RowFrag {
         return Mma<T>::load(row + (((e / VEC) ^ sw) * VEC) + (e % VEC));
     }
 };
-// WEIGHT operand of the split-bf16 mode: the pack kernel (optim.hip) already stores every 32-k block of a weight row
-// as [32 hi bf16][32 lo bf16] = the same 128 bytes the fp32 block would take, in the k order the activation fragment
-// above uses (16-byte slot g = k {4g..4g+3, 16+4g..16+4g+3}, hi in slots 0..3, lo in slots 4..7).  Its fragments are two
-// plain 16-byte reads and NO conversion: the weights are converted once per step by the pack launch instead of once per
-// wave, K step and tile that reads them (4 of the 6 fragments a 32x64 wave tile reads per K step are weights).
-__device__ __forceinline__ int x3_block_pos(int j) {              // position (bf16 index, 0..31) of k-in-block j inside a half
-    return ((j & 15) >> 2) * 8 + (j >> 4) * 4 + (j & 3);
-}
-template <class T> struct RowFragW {
-    static __device__ __forceinline__ typename Mma<T>::Frag load(const T* row, int ks, int g, int sw) { return RowFrag<T>::load(row, ks, g, sw); }
-};
-template <> struct RowFragW<f32x3_t> {
+// Split storage: the 128-byte row IS one 32-channel block [32 hi][32 lo]: lane group g takes slot g (hi of k = 8g .. 8g+7)
+// and slot g + 4 (their lo halves) -- two plain 16-byte reads, conflict-free under the XOR swizzle (two adjacent slots
+// are 2-way conflicted), NO conversion.  Activations arrive in this form from their producers, weights from the pack
+// launch (optim.hip).
+template <> struct RowFrag<f32x3_t> {
     static __device__ __forceinline__ Frag3 load(const f32x3_t* row, int ks, int g, int sw) {
-        (void)ks;
+        (void)ks;                                                        // KI = 32 = the whole 128-byte row
         Frag3 f;
         f.hi = load_bf16x8(row + ((g ^ sw) * 4));
         f.lo = load_bf16x8(row + (((g + 4) ^ sw) * 4));
         return f;
     }
 };
-template <> struct RowFrag<f32x3_t> {
-    static __device__ __forceinline__ Frag3 load(const f32x3_t* row, int ks, int g, int sw) {
-        (void)ks;                                                        // KI = 32 = the whole 128-byte row
-        const chunk16 c0 = *reinterpret_cast<const chunk16*>(row + ((g ^ sw) * 4));
-        const chunk16 c1 = *reinterpret_cast<const chunk16*>(row + (((g + 4) ^ sw) * 4));
-        return Mma<f32x3_t>::split2(c0, c1);
-    }
+template <class T> struct RowFragW {         // (weights and activations share one layout since round 4)
+    static __device__ __forceinline__ typename Mma<T>::Frag load(const T* row, int ks, int g, int sw) { return RowFrag<T>::load(row, ks, g, sw); }
 };
 
 // operand fragment read down the reduction (row) axis of a [rows][pitch] LDS tile;
@@ -297,14 +381,6 @@ template <class T, bool TR> struct ColFrag;
 template <bool TR> struct ColFrag<float, TR> {
     static __device__ __forceinline__ float load(const float* base, int pitch, int lane) {
         return base[(lane >> 4) * pitch + (lane & 15)];
-    }
-};
-template <bool TR> struct ColFrag<f32x3_t, TR> {     // rows k0 + g + 4 j, j = 0..7
-    static __device__ __forceinline__ Frag3 load(const f32x3_t* base, int pitch, int lane) {
-        const float* p = reinterpret_cast<const float*>(base) + (lane >> 4) * pitch + (lane & 15);
-        float x[8];
-        MTN_UNROLL for (int j = 0; j < 8; ++j) x[j] = p[4 * j * pitch];
-        return Mma<f32x3_t>::split(x);
     }
 };
 template <> struct ColFrag<bf16_t, false> {

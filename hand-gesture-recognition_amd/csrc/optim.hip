@@ -52,21 +52,22 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
                                                    T* __restrict__ dst, const int* __restrict__ desc) {
     const int* d = desc + blockIdx.y * 7;
     const int so = d[0], dof = d[1], O = d[2], I = d[3], taps = d[4], mode = d[5] & 1;
-    // split-bf16 mode (T = f32x3_t): a packed row of K values is stored as K / 32 blocks of [32 hi bf16][32 lo bf16] in the
-    // k order of the kernels' fragments (mtn_types.h RowFragW) unless the tensor asks for plain fp32 (d[5] & 2: the stem,
-    // whose kernels multiply in exact f32).  Same bytes, same offsets: element (row, k) of the fp32 layout becomes two
-    // bf16 at (row, block k / 32, x3_block_pos(k % 32)) of the hi and the lo half.
+    // split storage (T = f32x3_t): a packed row of K values is stored as K / 32 blocks of [32 hi bf16][32 lo bf16], k in
+    // natural order -- the layout of the activations (mtn_types.h) -- unless the tensor asks for plain fp32 (d[5] & 2: the
+    // stem, whose kernels multiply in exact f32).  Same bytes, same offsets: element (row, k) of the fp32 layout becomes
+    // two bf16 at (row, block k / 32, k % 32) of the hi and the lo half.
     constexpr bool X3 = std::is_same<T, f32x3_t>::value;
     const bool presplit = X3 && !(d[5] & 2);
     auto put = [&](long row_len, long row, int k, float v) {
         if (presplit) {
             bf16_t* base = reinterpret_cast<bf16_t*>(dst + dof + row * row_len + (k & ~31));
             const bf16_t h = f2bf(v);
-            const int pos = x3_block_pos(k & 31);
+            const int pos = k & 31;
             base[pos] = h;
             base[32 + pos] = f2bf(v - bf2f(h));
         } else {
-            dst[dof + row * row_len + k] = from_f<T>(v);
+            if constexpr (X3) reinterpret_cast<float*>(dst)[dof + row * row_len + k] = v;
+            else dst[dof + row * row_len + k] = from_f<T>(v);
         }
     };
     // d[6] >= 0: fold a per-output-channel factor scale[d[6] + o] into the weights (inference: the BatchNorm's

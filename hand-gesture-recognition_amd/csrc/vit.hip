@@ -13,27 +13,7 @@ namespace {
 constexpr int DIM = 256;
 constexpr int EPL = DIM / 64;        // elements per lane in a wave-per-row kernel
 
-template <class T> __device__ __forceinline__ void load_row4(const T* p, float* v);
-template <> __device__ __forceinline__ void load_row4<float>(const float* p, float* v) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-template <> __device__ __forceinline__ void load_row4<bf16_t>(const bf16_t* p, float* v) {
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    bf16_t a; a.v = (unsigned short)(t.x & 0xffff); v[0] = bf2f(a);
-    a.v = (unsigned short)(t.x >> 16); v[1] = bf2f(a);
-    a.v = (unsigned short)(t.y & 0xffff); v[2] = bf2f(a);
-    a.v = (unsigned short)(t.y >> 16); v[3] = bf2f(a);
-}
-template <class T> __device__ __forceinline__ void store_row4(T* p, const float* v);
-template <> __device__ __forceinline__ void store_row4<float>(float* p, const float* v) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <> __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, const float* v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)f2bf(v[0]).v | ((unsigned)f2bf(v[1]).v << 16),
-                                              (unsigned)f2bf(v[2]).v | ((unsigned)f2bf(v[3]).v << 16));
-}
-
+// a lane's four channels lane*EPL .. +3 of a row: ld4 / st4 (mtn_types.h; split storage: 8 bytes of the hi half and 8 of the lo half)
 // ---- token assembly ------------------------------------------------------------------------------
 // tokens[b][0] = cls ; tokens[b][1+p] = feat[b*P + p] + pos[p]
 template <class T>
@@ -47,10 +27,10 @@ __global__ __launch_bounds__(256) void tokens_fwd_kernel(const T* __restrict__ f
         if (t == 0) {
             MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] = cls[lane * EPL + e];
         } else {
-            load_row4<T>(feat + ((long)b * P + t - 1) * DIM + lane * EPL, v);
+            ld4<T>(feat + ((long)b * P + t - 1) * DIM, lane * EPL, v);
             MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] += pos[(t - 1) * DIM + lane * EPL + e];
         }
-        store_row4<T>(tok + r * DIM + lane * EPL, v);
+        st4<T>(tok + r * DIM, lane * EPL, v);
     }
 }
 // dfeat[b*P+p] = dtok[b][1+p]
@@ -61,8 +41,8 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const T* __restrict__ d
     for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
         const int b = (int)(r / P), p = (int)(r - (long)b * P);
         float v[EPL];
-        load_row4<T>(dtok + ((long)b * (P + 1) + 1 + p) * DIM + lane * EPL, v);
-        store_row4<T>(dfeat + r * DIM + lane * EPL, v);
+        ld4<T>(dtok + ((long)b * (P + 1) + 1 + p) * DIM, lane * EPL, v);
+        st4<T>(dfeat + r * DIM, lane * EPL, v);
     }
 }
 // dcls[c] = sum_b dtok[b][0][c]   (one 1024-thread block: 4 batch lanes x 256 channels)
@@ -71,7 +51,7 @@ __global__ __launch_bounds__(1024) void cls_grad_kernel(const T* __restrict__ dt
     __shared__ float red[4][DIM];
     const int c = threadIdx.x & 255, bq = threadIdx.x >> 8;
     float s = 0.f;
-    for (int b = bq; b < B; b += 4) s += to_f<T>(dtok[(long)b * (P + 1) * DIM + c]);
+    for (int b = bq; b < B; b += 4) s += ld1<T>(dtok + (long)b * (P + 1) * DIM, c);
     red[bq][c] = s;
     __syncthreads();
     if (bq == 0) dcls[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
@@ -87,13 +67,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
     MTN_UNROLL for (int e = 0; e < EPL; ++e) { gm[e] = gamma[lane * EPL + e]; bt[e] = beta[lane * EPL + e]; }
     for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += (long)gridDim.x * 4) {
         float v[EPL];
-        load_row4<T>(x + r * ldx + lane * EPL, v);
+        ld4<T>(x + r * ldx, lane * EPL, v);
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DIM);
         float d = 0.f;
         MTN_UNROLL for (int e = 0; e < EPL; ++e) { v[e] -= mean; d += v[e] * v[e]; }
         const float rstd = rsqrtf(wave_sum(d) * (1.0f / DIM) + eps);
         MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] = v[e] * rstd * gm[e] + bt[e];
-        store_row4<T>(y + r * ldy + lane * EPL, v);
+        st4<T>(y + r * ldy, lane * EPL, v);
         if (mean_rstd && lane == 0) { mean_rstd[2 * r] = mean; mean_rstd[2 * r + 1] = rstd; }
     }
 }
@@ -114,8 +94,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     if (r1 > M) r1 = M;
     for (long r = r0 + w; r < r1; r += 4) {
         float g[EPL], xv[EPL];
-        load_row4<T>(dy + r * lddy + lane * EPL, g);
-        load_row4<T>(x + r * ldx + lane * EPL, xv);
+        ld4<T>(dy + r * lddy, lane * EPL, g);
+        ld4<T>(x + r * ldx, lane * EPL, xv);
         const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
         float a = 0.f, b = 0.f;
         MTN_UNROLL for (int e = 0; e < EPL; ++e) {
@@ -131,10 +111,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] = rstd * (g[e] - a - xv[e] * b);
         if (dres) {
             float rr[EPL];
-            load_row4<T>(dres + r * lddres + lane * EPL, rr);
+            ld4<T>(dres + r * lddres, lane * EPL, rr);
             MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] += rr[e];
         }
-        store_row4<T>(dx + r * lddx + lane * EPL, g);
+        st4<T>(dx + r * lddx, lane * EPL, g);
     }
     MTN_UNROLL for (int e = 0; e < EPL; ++e) { red[w][0][lane * EPL + e] = sg[e]; red[w][1][lane * EPL + e] = sb[e]; }
     __syncthreads();
@@ -148,13 +128,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
 template <class T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ a, T* __restrict__ da,
                                                        long nchunks) {
-    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int VEC = Ev<T>::N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const long e0 = i * VEC, blk = e0 & ~31L;             // (whole 32-channel blocks: valid for split storage too)
+        const int c = (int)(e0 & 31);
         float g[VEC], v[VEC];
-        unpack<T>(reinterpret_cast<const chunk16*>(dh)[i], g);
-        unpack<T>(reinterpret_cast<const chunk16*>(a)[i], v);
+        ld_vec<T>(dh + blk, c, g);
+        ld_vec<T>(a + blk, c, v);
         MTN_UNROLL for (int e = 0; e < VEC; ++e) g[e] *= gelu_grad_(v[e]);
-        reinterpret_cast<chunk16*>(da)[i] = pack<T>(g);
+        st_vec<T>(da + blk, c, g);
     }
 }
 
@@ -171,7 +153,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     if (r1 > M) r1 = M;
     for (long r = r0 + w; r < r1; r += 4) {
         float v[EPL];
-        load_row4<T>(x + r * ldx + lane * EPL, v);
+        ld4<T>(x + r * ldx, lane * EPL, v);
         MTN_UNROLL for (int e = 0; e < EPL; ++e) s[e] += v[e];
     }
     MTN_UNROLL for (int e = 0; e < EPL; ++e) red[w][lane * EPL + e] = s[e];
@@ -190,7 +172,7 @@ __global__ __launch_bounds__(64) void cls_head_fwd_kernel(const T* __restrict__ 
                                                           float eps) {
     const int lane = threadIdx.x, b = blockIdx.x;
     float v[EPL];
-    load_row4<T>(tok + (long)b * tok_stride + lane * EPL, v);
+    ld4<T>(tok + (long)b * tok_stride, lane * EPL, v);
     const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DIM);
     float d = 0.f;
     MTN_UNROLL for (int e = 0; e < EPL; ++e) { v[e] -= mean; d += v[e] * v[e]; }
@@ -234,7 +216,7 @@ __global__ __launch_bounds__(64) void cls_head_bwd_x_kernel(const float* __restr
     bb = wave_sum(bb) * (1.0f / DIM);
     const float rstd = mean_rstd[2 * b + 1];
     MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] = rstd * (g[e] - a - xh[e] * bb);
-    store_row4<T>(dtok + (long)b * tok_stride + lane * EPL, g);
+    st4<T>(dtok + (long)b * tok_stride, lane * EPL, g);
 }
 
 // block c (1024 threads = 4 batch lanes x 256 features): dW[c][k] = sum_b dl[b][c]*xn[b][k], dbias[c] = sum_b dl[b][c]
@@ -259,6 +241,31 @@ __global__ __launch_bounds__(1024) void cls_head_bwd_w_kernel(const float* __res
     }
 }
 
+// ---- split storage <-> plain f32 (module boundary: backbone features handed to / gradients taken from the caller; the pose
+// head, whose kernels keep plain f32 operands) ------------------------------------------------------------------------------
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void x3_convert_kernel(const void* __restrict__ src, int lds_, void* __restrict__ dst, int ldd,
+                                                         long M, int C) {
+    const int gpr = C / 8;                                      // 8-channel groups per row
+    const long total = M * gpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / gpr;
+        const int c = (int)(i - m * gpr) * 8;
+        float v[8];
+        if (SPLIT) {
+            const float* s = reinterpret_cast<const float*>(src) + m * lds_ + c;
+            unpack<float>(*reinterpret_cast<const chunk16*>(s), v);
+            unpack<float>(*reinterpret_cast<const chunk16*>(s + 4), v + 4);
+            st_vec<f32x3_t>(reinterpret_cast<f32x3_t*>(dst) + m * ldd, c, v);
+        } else {
+            ld_vec<f32x3_t>(reinterpret_cast<const f32x3_t*>(src) + m * lds_, c, v);
+            float* d = reinterpret_cast<float*>(dst) + m * ldd + c;
+            *reinterpret_cast<chunk16*>(d) = pack<float>(v);
+            *reinterpret_cast<chunk16*>(d + 4) = pack<float>(v + 4);
+        }
+    }
+}
+
 inline int row_grid(long rows) {
     long b = (rows + 3) / 4;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -277,6 +284,8 @@ int mtn_tokens_fwd_run(const void* feat, const float* pos, const float* cls, voi
     MTN_REQUIRE(B > 0 && P > 0, "tokens_fwd: bad sizes");
     if (dtype == MTN_BF16)
         MTN_LAUNCH(tokens_fwd_kernel<bf16_t>, dim3(row_grid((long)B * (P + 1))), dim3(256), 0, stream, (const bf16_t*)feat, pos, cls, (bf16_t*)tok, B, P);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(tokens_fwd_kernel<f32x3_t>, dim3(row_grid((long)B * (P + 1))), dim3(256), 0, stream, (const f32x3_t*)feat, pos, cls, (f32x3_t*)tok, B, P);
     else
         MTN_LAUNCH(tokens_fwd_kernel<float>, dim3(row_grid((long)B * (P + 1))), dim3(256), 0, stream, (const float*)feat, pos, cls, (float*)tok, B, P);
     return mtn_check_launch("tokens_fwd");
@@ -287,6 +296,9 @@ int mtn_tokens_bwd_run(const void* dtok, void* dfeat, float* dcls, int dtype, in
     if (dtype == MTN_BF16) {
         MTN_LAUNCH(tokens_bwd_kernel<bf16_t>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const bf16_t*)dtok, (bf16_t*)dfeat, B, P);
         MTN_LAUNCH(cls_grad_kernel<bf16_t>, dim3(1), dim3(1024), 0, stream, (const bf16_t*)dtok, dcls, B, P);
+    } else if (dtype == MTN_F32X3) {
+        MTN_LAUNCH(tokens_bwd_kernel<f32x3_t>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const f32x3_t*)dtok, (f32x3_t*)dfeat, B, P);
+        MTN_LAUNCH(cls_grad_kernel<f32x3_t>, dim3(1), dim3(1024), 0, stream, (const f32x3_t*)dtok, dcls, B, P);
     } else {
         MTN_LAUNCH(tokens_bwd_kernel<float>, dim3(row_grid((long)B * P)), dim3(256), 0, stream, (const float*)dtok, (float*)dfeat, B, P);
         MTN_LAUNCH(cls_grad_kernel<float>, dim3(1), dim3(1024), 0, stream, (const float*)dtok, dcls, B, P);
@@ -299,6 +311,8 @@ int mtn_ln_fwd_run(const void* x, int ldx, const float* gamma, const float* beta
     MTN_REQUIRE(M > 0 && ldx % 4 == 0 && ldy % 4 == 0, "ln_fwd: bad sizes");
     if (dtype == MTN_BF16)
         MTN_LAUNCH(ln_fwd_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean_rstd, M, eps);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(ln_fwd_kernel<f32x3_t>, dim3(row_grid(M)), dim3(256), 0, stream, (const f32x3_t*)x, ldx, gamma, beta, (f32x3_t*)y, ldy, mean_rstd, M, eps);
     else
         MTN_LAUNCH(ln_fwd_kernel<float>, dim3(row_grid(M)), dim3(256), 0, stream, (const float*)x, ldx, gamma, beta, (float*)y, ldy, mean_rstd, M, eps);
     return mtn_check_launch("ln_fwd");
@@ -315,6 +329,9 @@ int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float
     if (dtype == MTN_BF16)
         MTN_LAUNCH(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean_rstd,
                    gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partial, M, kLnRows);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(ln_bwd_kernel<f32x3_t>, dim3(blocks), dim3(256), 0, stream, (const f32x3_t*)dy, lddy, (const f32x3_t*)x, ldx, mean_rstd,
+                   gamma, (const f32x3_t*)dres, lddres, (f32x3_t*)dx, lddx, partial, M, kLnRows);
     else
         MTN_LAUNCH(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, (const float*)x, ldx, mean_rstd,
                    gamma, (const float*)dres, lddres, (float*)dx, lddx, partial, M, kLnRows);
@@ -325,13 +342,15 @@ int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float
 }
 
 int mtn_gelu_bwd_run(const void* dh, const void* a, void* da, int dtype, long n, hipStream_t stream) {
-    const int vec = dtype == MTN_BF16 ? 8 : 4;
+    const int vec = dtype == MTN_F32 ? 4 : (dtype == MTN_F32X3 ? 32 : 8);
     MTN_REQUIRE(n > 0 && n % vec == 0, "gelu_bwd: n=%ld must be a multiple of %d", n, vec);
-    const long chunks = n / vec;
+    const long chunks = n / (dtype == MTN_F32 ? 4 : 8);
     long blocks = (chunks + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (dtype == MTN_BF16)
         MTN_LAUNCH(gelu_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)dh, (const bf16_t*)a, (bf16_t*)da, chunks);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(gelu_bwd_kernel<f32x3_t>, dim3((int)blocks), dim3(256), 0, stream, (const f32x3_t*)dh, (const f32x3_t*)a, (f32x3_t*)da, chunks);
     else
         MTN_LAUNCH(gelu_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, (const float*)dh, (const float*)a, (float*)da, chunks);
     return mtn_check_launch("gelu_bwd");
@@ -342,6 +361,8 @@ int mtn_bias_grad_run(const void* dy, int lddy, float* partial, float* dbias, in
     const int blocks = mtn_rowslab_blocks(M);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(colsum_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, partial, M, kLnRows);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(colsum_partial_kernel<f32x3_t>, dim3(blocks), dim3(256), 0, stream, (const f32x3_t*)dy, lddy, partial, M, kLnRows);
     else
         MTN_LAUNCH(colsum_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, partial, M, kLnRows);
     int rc = mtn_check_launch("bias_grad");
@@ -356,6 +377,8 @@ int mtn_cls_head_fwd_run(const void* tok, long tok_stride, const float* lg, cons
     MTN_REQUIRE(B > 0 && C > 0, "cls_head_fwd: bad sizes");
     if (dtype == MTN_BF16)
         MTN_LAUNCH(cls_head_fwd_kernel<bf16_t>, dim3(B), dim3(64), 0, stream, (const bf16_t*)tok, tok_stride, lg, lb, W, bias, logits, xhat, mean_rstd, C, eps);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(cls_head_fwd_kernel<f32x3_t>, dim3(B), dim3(64), 0, stream, (const f32x3_t*)tok, tok_stride, lg, lb, W, bias, logits, xhat, mean_rstd, C, eps);
     else
         MTN_LAUNCH(cls_head_fwd_kernel<float>, dim3(B), dim3(64), 0, stream, (const float*)tok, tok_stride, lg, lb, W, bias, logits, xhat, mean_rstd, C, eps);
     return mtn_check_launch("cls_head_fwd");
@@ -367,10 +390,24 @@ int mtn_cls_head_bwd_run(const float* dlogits, const float* W, const float* lg, 
     MTN_REQUIRE(B > 0 && C > 0, "cls_head_bwd: bad sizes");
     if (dtype == MTN_BF16)
         MTN_LAUNCH(cls_head_bwd_x_kernel<bf16_t>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (bf16_t*)dtok, tok_stride, partial, C);
+    else if (dtype == MTN_F32X3)
+        MTN_LAUNCH(cls_head_bwd_x_kernel<f32x3_t>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (f32x3_t*)dtok, tok_stride, partial, C);
     else
         MTN_LAUNCH(cls_head_bwd_x_kernel<float>, dim3(B), dim3(64), 0, stream, dlogits, W, lg, xhat, mean_rstd, (float*)dtok, tok_stride, partial, C);
     MTN_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(1024), 0, stream, dlogits, lg, lb, xhat, dW, dbias, B, C);
     int rc = mtn_check_launch("cls_head_bwd");
     if (rc) return rc;
     return mtn_colsum_run(partial, B, 2 * DIM, dlg_dlb, stream);
+}
+
+int mtn_x3_convert_run(const void* src, int ld_src, void* dst, int ld_dst, int to_split, long M, int C, hipStream_t stream) {
+    MTN_REQUIRE(M > 0 && C > 0 && C % 32 == 0 && ld_src % 32 == 0 && ld_dst % 32 == 0 && ld_src >= C && ld_dst >= C,
+                "x3_convert: rows of whole 32-channel blocks only (C=%d, pitches %d / %d)", C, ld_src, ld_dst);
+    MTN_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "x3_convert: operands must be 16-byte aligned");
+    const long total = M * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (to_split) MTN_LAUNCH(x3_convert_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, M, C);
+    else MTN_LAUNCH(x3_convert_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, M, C);
+    return mtn_check_launch("x3_convert");
 }

@@ -201,14 +201,6 @@ template <int ROWE> struct ColFragS<float, ROWE> {
         return tile[Swz<float, ROWE>::off(k0 + (lane >> 4), col0 + (lane & 15))];
     }
 };
-template <int ROWE> struct ColFragS<f32x3_t, ROWE> {       // rows k0 + g + 4 j, j = 0..7 (Mma<f32x3_t>, mtn_types.h)
-    static __device__ __forceinline__ Frag3 load(const f32x3_t* tile, int k0, int col0, int lane) {
-        const float* t = reinterpret_cast<const float*>(tile);
-        float x[8];
-        MTN_UNROLL for (int j = 0; j < 8; ++j) x[j] = t[Swz<float, ROWE>::off(k0 + (lane >> 4) + 4 * j, col0 + (lane & 15))];
-        return Mma<f32x3_t>::split(x);
-    }
-};
 template <int ROWE> struct ColFragS<bf16_t, ROWE> {
     static __device__ __forceinline__ bf16x8_t load(const bf16_t* tile, int k0, int col0, int lane) {
         const int g = lane >> 4, i = lane & 15;
@@ -226,6 +218,21 @@ template <int ROWE> struct ColFragS<bf16_t, ROWE> {
         const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p1));
         f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 #endif
+        return f;
+    }
+};
+
+// Split storage: a tile row of ROWE channels is ROWE / 32 blocks [32 hi][32 lo] = a bf16 row of 2 ROWE columns in which channel
+// c sits at column x3_pos(c) (hi) and x3_pos(c) + 32 (lo).  The DMA moved the bytes as they are and swizzled 32-byte units
+// by row (Swz<f32x3_t, ROWE> and Swz<bf16_t, 2 ROWE> are the same byte map), so the hi and the lo fragment of 16 channels are
+// the bf16 mode's transposing reads at two columns: lane group g gets pixels k0 + 8g .. 8g+7, no conversion.
+template <int ROWE> struct ColFragS<f32x3_t, ROWE> {
+    static __device__ __forceinline__ Frag3 load(const f32x3_t* tile, int k0, int col0, int lane) {
+        const bf16_t* t = reinterpret_cast<const bf16_t*>(tile);
+        const int hc = x3_pos(col0);
+        Frag3 f;
+        f.hi = ColFragS<bf16_t, 2 * ROWE>::load(t, k0, hc, lane);
+        f.lo = ColFragS<bf16_t, 2 * ROWE>::load(t, k0, hc + 32, lane);
         return f;
     }
 };
@@ -699,22 +706,51 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
     MTN_UNROLL for (int t = 0; t < 9; ++t) { acc[t][0] = zero4(); acc[t][1] = zero4(); }
     // operand fragment offsets (elements) at K-sub-step 0: rows advance by SUB per sub-step, which
     // leaves the swizzle (a function of row bits 0..3) unchanged -> the sub-step is an address immediate
+    // (split storage: offsets in bf16 units of the SAME byte image -- a 64-channel row is 128 bf16 columns, channel c's hi half
+    //  at column x3_pos(c); the lo half sits two 32-byte units further, which under the XOR swizzle of the unit index is the
+    //  hi offset ^ 32: the unit index of a hi half has bit 1 clear)
+    constexpr bool X3 = std::is_same<T, f32x3_t>::value;
+    constexpr int RE = X3 ? 128 : 64;                             // bf16 columns of a tile row
+    typedef Swz<bf16_t, RE> SWB;
     int yoff[2][2], xoff[9][2];
-    if (sizeof(T) == 2) {
+    if (sizeof(T) == 2 || X3) {
         const int g = lane >> 4, i16 = lane & 15;
         const int r0 = 8 * g + (i16 >> 2), cc = 4 * (i16 & 3);
         MTN_UNROLL for (int i = 0; i < 2; ++i) {
-            yoff[i][0] = SW::off(r0, (nh * 2 + i) * 16 + cc);
-            yoff[i][1] = SW::off(r0 + 4, (nh * 2 + i) * 16 + cc);
+            const int col = X3 ? x3_pos((nh * 2 + i) * 16) : (nh * 2 + i) * 16;
+            yoff[i][0] = SWB::off(r0, col + cc);
+            yoff[i][1] = SWB::off(r0 + 4, col + cc);
         }
         MTN_UNROLL for (int t = 0; t < 9; ++t) {
             const int sh = HALO + (t / 3 - 1) * W1 + (t % 3 - 1);
-            xoff[t][0] = KS * 64 + SW::off(r0 + sh, cf * 16 + cc);
-            xoff[t][1] = KS * 64 + SW::off(r0 + 4 + sh, cf * 16 + cc);
+            const int col = X3 ? x3_pos(cf * 16) : cf * 16;
+            xoff[t][0] = KS * RE + SWB::off(r0 + sh, col + cc);
+            xoff[t][1] = KS * RE + SWB::off(r0 + 4 + sh, col + cc);
         }
     }
+    auto tr_pair = [&](const bf16_t* q0, const bf16_t* q1) -> bf16x8_t {
+        bf16x8_t f;
+#ifdef MTN_EMU
+        emu::u16x4 a = emu::ds_read_tr16_b64(q0), b = emu::ds_read_tr16_b64(q1);
+        MTN_UNROLL for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+#else
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) bf16x4_t* lds_ptr;
+        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(q0));
+        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(q1));
+        f = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+        return f;
+    };
     auto frag = [&](const T* tile, int e0, int e1, int row, int col) -> typename Mma<T>::Frag {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (X3) {
+            (void)row; (void)col;
+            const bf16_t* t = reinterpret_cast<const bf16_t*>(tile);
+            Frag3 f;
+            f.hi = tr_pair(t + e0, t + e1);
+            f.lo = tr_pair(t + (e0 ^ 32), t + (e1 ^ 32));
+            return f;
+        } else if constexpr (sizeof(T) == 2) {
             (void)row; (void)col;
             const bf16_t* q0 = reinterpret_cast<const bf16_t*>(tile) + e0;
             const bf16_t* q1 = reinterpret_cast<const bf16_t*>(tile) + e1;
@@ -756,6 +792,16 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
                 MTN_UNROLL for (int t = 0; t < 9; ++t)
                     MTN_UNROLL for (int i = 0; i < 2; ++i) acc[t][i] = Mma<T>::mma(fx[j & 1][t], fy[j & 1][i], acc[t][i]);
                 MTN_SCHED_FENCE();
+            }
+        } else if constexpr (X3) {
+            // one register set (a Frag3 is 8 registers: two sets of 11 would not leave room for the 18 accumulator quads)
+            MTN_UNROLL for (int j = 0; j < NSUB; ++j) {
+                Frag3 fy[2];
+                MTN_UNROLL for (int i = 0; i < 2; ++i) fy[i] = frag(rd, yoff[i][0] + j * SUB * RE, yoff[i][1] + j * SUB * RE, 0, 0);
+                MTN_UNROLL for (int t = 0; t < 9; ++t) {
+                    const Frag3 fx = frag(rd, xoff[t][0] + j * SUB * RE, xoff[t][1] + j * SUB * RE, 0, 0);
+                    MTN_UNROLL for (int i = 0; i < 2; ++i) acc[t][i] = Mma<T>::mma(fx, fy[i], acc[t][i]);
+                }
             }
         } else {
             MTN_UNROLL for (int j = 0; j < NSUB; ++j) {
@@ -984,18 +1030,24 @@ template <class T, bool TR>
 static int wgrad_dispatch(const WgradArgs& p, hipStream_t stream) {
     int bn, bc;
     wgrad_tile(p.N, p.Cin, &bn, &bc);
-    if (g_wgrad_dma && (TR || sizeof(T) == 4)) {
+    constexpr bool x3_ = std::is_same<T, f32x3_t>::value;
+    if ((g_wgrad_dma || x3_) && (TR || sizeof(T) == 4)) {     // (split storage has no register-staged form)
         // 8 waves (4 DMA pieces per wave per step instead of 8: the issue of an LDS-DMA instruction
         // costs its wave ~100 cycles); debug key 7 = 4 selects the 4-wave layout (+5..9 % slower)
-        // (split-bf16 mode: 4 waves of 64 x 64 -- 8 fragment conversions per 48 MFMAs instead of 6 per 24: step 23.06 -> 22.68 ms)
+        // (split storage: the fragments need no conversion since round 4, so it takes the 8-wave layout like bf16; until then
+        //  4 waves of 64 x 64 -- 8 fragment conversions per 48 MFMAs instead of 6 per 24 -- were 2 % faster)
         constexpr bool x3 = std::is_same<T, f32x3_t>::value;
-        if (bn == 128 && bc == 128) return (g_wgrad_tile == 4 || x3) ? launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream) : launch_wgrad_dma<T, 128, 128, 4, 2>(p, stream);
+        (void)x3;
+        if (bn == 128 && bc == 128) return g_wgrad_tile == 4 ? launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream) : launch_wgrad_dma<T, 128, 128, 4, 2>(p, stream);
         if (bn == 128) return launch_wgrad_dma<T, 128, 64, 4, 1>(p, stream);
         return launch_wgrad_dma<T, 64, 64, 2, 2>(p, stream);
     }
-    if (bn == 128 && bc == 128) return launch_wgrad<T, 128, 128, 2, 2, TR>(p, stream);
-    if (bn == 128) return launch_wgrad<T, 128, 64, 4, 1, TR>(p, stream);
-    return launch_wgrad<T, 64, 64, 2, 2, TR>(p, stream);
+    if constexpr (!x3_) {
+        if (bn == 128 && bc == 128) return launch_wgrad<T, 128, 128, 2, 2, TR>(p, stream);
+        if (bn == 128) return launch_wgrad<T, 128, 64, 4, 1, TR>(p, stream);
+        return launch_wgrad<T, 64, 64, 2, 2, TR>(p, stream);
+    }
+    return MTN_ERR_UNSUPPORTED;
 }
 
 int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
@@ -1012,6 +1064,8 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
                 "wgrad3: bad split (%d x %d slots)", p.splits, p.rows_per_split);
     MTN_REQUIRE(!row3 || (p.KH == 3 && p.KW == 3 && p.N % 128 == 0), "wgrad_row3: 3x3 layers with 128-wide outputs only");
     MTN_REQUIRE(((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0, "wgrad: pointers must be 16-byte aligned");
+    MTN_REQUIRE(dtype != MTN_F32X3 || ((((uintptr_t)p.dY | (uintptr_t)p.X) % 16 == 0) && p.lddy % 32 == 0 && p.ldx % 32 == 0),
+                "wgrad: split storage (MTN_DTYPE_F32X3) needs 16-byte aligned operands and row pitches that are multiples of 32");
     MTN_REQUIRE((p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) ||
                     (((long)p.M + 128) * p.OW < (1L << 32) && ((long)p.M / p.OW + 128) * p.OH < (1L << 32)),
                 "wgrad: M * OW too large for the multiply-high pixel walk");

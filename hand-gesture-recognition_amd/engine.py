@@ -24,22 +24,6 @@ from . import ops
 _ACT = {True: ops.ACT_SILU, False: ops.ACT_NONE}
 
 
-def _in_plan_mode(fn):
-    """Run an Engine method with ops' fp32-matmul mode set to the plan's (exact-f32 MFMA or split-bf16) and
-    restore the caller's afterwards: the mode is not a property of the fp32 tensors the wrappers see."""
-    import functools
-
-    @functools.wraps(fn)
-    def inner(self, *a, **k):
-        prev = ops._f32_code
-        ops.set_f32_matmul(self.f32_code)
-        try:
-            return fn(self, *a, **k)
-        finally:
-            ops.set_f32_matmul(prev)
-    return inner
-
-
 class _Unit:
     """One Conv2d(+BatchNorm) site and its per-layer buffers."""
 
@@ -53,7 +37,11 @@ class Engine:
     def __init__(self, model, batch, dtype):
         from .multitasknet import resolve_compute_dtype
         self.model, self.B = model, int(batch)
-        self.dt, self.f32_code = resolve_compute_dtype(dtype)      # storage dtype, how fp32 operands are multiplied
+        self.dt, self.f32_code = resolve_compute_dtype(dtype)      # torch dtype of the buffers, what an fp32 buffer holds
+        # the wrappers with this plan's mode bound (ops.with_mode): what a torch.float32 buffer of the plan holds -- plain fp32
+        # or split storage -- travels with every call, like the dtype argument of the C ABI (no process-wide state)
+        self.o = ops.with_mode(self.f32_code)
+        self.x3 = self.dt == torch.float32 and self.f32_code == ops.F32X3
         self.dev = model.flat_params.device
         self.generation = model._generation       # the flat buffers this plan's pointers were taken from
         H, W = model.image_size
@@ -85,7 +73,6 @@ class Engine:
     def _f32(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
 
-    @_in_plan_mode
     def _build(self):
         B, enc = self.B, self.model.encoder
         H2, W2 = self.H // 2, self.W // 2
@@ -123,6 +110,9 @@ class Engine:
 
         def add_pack(p, O, I, taps, mode):
             nonlocal off
+            if self.x3 and not (mode & 2) and ((O if mode & 1 else I) * taps) % 32:
+                raise ValueError(f"split storage packs weight rows in 32-element blocks: {tuple(p.shape)} has rows of "
+                                 f"{(O if mode & 1 else I) * taps} (use compute_dtype=torch.float32 for this model variant)")
             src = (p.data_ptr() - flat.data_ptr()) // 4
             desc.append([src, off, O, I, taps, mode, -1])
             o = off
@@ -186,26 +176,26 @@ class Engine:
             # recomputed from the image instead of stored
             u.raw = self._new((B, u.hout, u.wout, u.cout)) if u is not self.u_conv1 else None
             if u.bn:
-                tiles = ops.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else ops.conv_fwd_stats_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
+                tiles = self.o.conv1_stats_tiles(B, self.H, self.W) if u is self.u_conv1 else self.o.conv_fwd_stats_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
                 u.tiles = tiles
-                u.stats = self._f32(ops.slab_rows(tiles), 2, u.cout)
+                u.stats = self._f32(self.o.slab_rows(tiles), 2, u.cout)
                 fo = self._fold_off[id(u)]
                 u.ss = self.fold[fo:fo + 2 * u.cout].view(2, u.cout)
                 u.mr, u.coef = self._f32(2, u.cout), self._f32(2, u.cout)
                 if u is not self.u_conv1:
-                    max_part = max(max_part, ops.bn_bwd_partial_rows(M) * 2 * u.cout)
+                    max_part = max(max_part, self.o.bn_bwd_partial_rows(M) * 2 * u.cout)
             u.pre_rows = 0      # > 0: the data gradient that produced this unit's output gradient left that many rows of BN-backward sums in bn_part
             if u is self.u_conv1:
-                self.conv1_part = self._f32(*ops.conv1_bwd_partial_shape(B, self.H, self.W))
+                self.conv1_part = self._f32(*self.o.conv1_bwd_partial_shape(B, self.H, self.W))
             else:
                 # rows of BatchNorm-backward sums this unit's data gradient writes for the unit consuming it (conv_dgrad(bn=...))
-                u.dgrad_tiles = ops.conv_dgrad_bn_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
-                max_part = max(max_part, ops.slab_rows(u.dgrad_tiles) * 2 * u.cin)
+                u.dgrad_tiles = self.o.conv_dgrad_bn_tiles(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s)
+                max_part = max(max_part, self.o.slab_rows(u.dgrad_tiles) * 2 * u.cin)
                 max_dy = max(max_dy, M * u.cout)
-                max_ws = max(max_ws, ops.conv_wgrad_workspace_bytes(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s))
+                max_ws = max(max_ws, self.o.conv_wgrad_workspace_bytes(self.dt, B, u.hin, u.win, u.cin, u.cout, u.k, u.s))
         Mt = B * self.N
         for n_out, k_in in ((768, 256), (256, 256)):
-            max_ws = max(max_ws, ops.linear_wgrad_workspace_bytes(self.dt, Mt, n_out, k_in))
+            max_ws = max(max_ws, self.o.linear_wgrad_workspace_bytes(self.dt, Mt, n_out, k_in))
         self.dyraw = self._new((max_dy,))
         self.bn_part = self._f32(max_part)
         self.wgrad_ws = self._f32(max_ws // 4 + 4)
@@ -244,32 +234,35 @@ class Engine:
         self.t_a, self.t_b = self._new((Mt, D)), self._new((Mt, D))     # backward temporaries
         self.t_qkv = self._new((Mt, 3 * D))
         self.delta = self._f32(B * self.heads, self.N)
-        self.row_part = self._f32(ops.rowslab_rows(Mt), 2 * D)
+        self.row_part = self._f32(self.o.rowslab_rows(Mt), 2 * D)
         mlp = self.layers[0]["fc1"].out_features
-        self.gelu_tiles = ops.linear_gelu_bwd_tiles(Mt, mlp, D)
-        self.gelu_part = self._f32(ops.slab_rows(self.gelu_tiles), 2, mlp)
+        self.gelu_tiles = self.o.linear_gelu_bwd_tiles(Mt, mlp, D)
+        self.gelu_part = self._f32(self.o.slab_rows(self.gelu_tiles), 2, mlp)
         self.leaf_plan = None
         if self.defer_leaf_sums and self.fuse_gelu_bwd:
             # one slab per producer (they stay unreduced until the end of the ViT backward) + the table of folds
-            prod, jobs = ops.rowslab_producer_rows(Mt), []
+            prod, jobs = self.o.rowslab_producer_rows(Mt), []
             for L in self.layers:
                 at, ff = L["attn"], L["ff"]
-                L["p_ln1"], L["p_ln2"] = self._f32(ops.rowslab_rows(Mt), 2 * D), self._f32(ops.rowslab_rows(Mt), 2 * D)
-                L["p_b2"] = self._f32(ops.rowslab_rows(Mt), D)
-                L["p_gelu"] = self._f32(ops.slab_rows(self.gelu_tiles), 2, mlp)
+                L["p_ln1"], L["p_ln2"] = self._f32(self.o.rowslab_rows(Mt), 2 * D), self._f32(self.o.rowslab_rows(Mt), 2 * D)
+                L["p_b2"] = self._f32(self.o.rowslab_rows(Mt), D)
+                L["p_gelu"] = self._f32(self.o.slab_rows(self.gelu_tiles), 2, mlp)
                 jobs.append((L["p_ln1"], prod, 2 * D, 2 * D, self._pair(at.norm.weight, at.norm.bias)))
                 jobs.append((L["p_ln2"], prod, 2 * D, 2 * D, self._pair(ff.net[0].weight, ff.net[0].bias)))
                 jobs.append((L["p_b2"], prod, D, D, self._g(ff.net[4].bias)))
                 jobs.append((L["p_gelu"], self.gelu_tiles, mlp, 2 * mlp, self._g(ff.net[1].bias)))      # the sum half of [2][mlp] rows
-            self.leaf_plan = ops.ColsumPlan(jobs)
+            self.leaf_plan = self.o.ColsumPlan(jobs)
+        # the pose head's kernels take plain f32 tokens (include/mtn.h): split storage converts at that boundary
+        self.xl_plain = self._f32(B, self.N, D) if self.x3 else None
+        self.G_plain = self._f32(B, self.N, D) if self.x3 else None
         self.attn = self._f32(B, self.heads, self.N, self.N)
         self.logits = self._f32(B, self.C)
         self.hm = self._f32(B, self.J, 4 * self.fh, 4 * self.fw)
         self.cls_xhat, self.cls_mr = self._f32(B, D), self._f32(B, 2)
-        self.cls_part = self._f32(ops.slab_rows(B), 2 * D)
-        self.pose_slab = self._f32(ops.slab_rows(B), self.J * (D + 1))
+        self.cls_part = self._f32(self.o.slab_rows(B), 2 * D)
+        self.pose_slab = self._f32(self.o.slab_rows(B), self.J * (D + 1))
         self.dlogits, self.dhm = self._f32(B, self.C), torch.empty_like(self.hm)
-        self.loss_part = self._f32(ops.loss_partial_len(self.hm.numel()))
+        self.loss_part = self._f32(self.o.loss_partial_len(self.hm.numel()))
         self.losses = self._f32(3)
 
     # ---------------------------------------------------------------- helpers
@@ -286,23 +279,21 @@ class Engine:
                                "(load_state_dict(assign=True) / .to() / _flatten()); take a new one with "
                                "model.engine(batch) and rebuild the TrainStep")
 
-    @_in_plan_mode
     def pack_weights(self, folded=False):
         """Refresh the kernels' copy of the weights from the fp32 masters.  ``folded`` (inference): every Conv
         unit's BatchNorm scale -- its u.ss[0], filled by bn_eval_scale_shift before this call -- is multiplied
         into its forward weights."""
         self.check_current()
-        ops.pack_weights(self.model.flat_params, self.wpack, self.pack_desc_eval if folded else self.pack_desc,
+        self.o.pack_weights(self.model.flat_params, self.wpack, self.pack_desc_eval if folded else self.pack_desc,
                          self.pack_n, self.pack_max, scale=self.fold if folded else None)
 
-    @_in_plan_mode
     def fold_batchnorm(self):
         """eval(): scale / shift of every BatchNorm from its running statistics, then the packed weights with the
         scale folded in -- after this the forward has no BatchNorm pass at all (export.py:41-45)."""
         for u in self.units:
             if u.bn:
                 bn = u.mod.bn
-                ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, u.ss, bn.eps)
+                self.o.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, u.ss, bn.eps)
         self.pack_weights(folded=True)
 
     def _dy(self, u):
@@ -311,30 +302,30 @@ class Engine:
     def _bn_fwd(self, u, out, res=None):
         """train mode: batch statistics from the conv epilogue's partial sums, then normalise + activation"""
         bn = u.mod.bn
-        ops.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+        self.o.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                         bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
-        ops.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
+        self.o.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
 
     def _conv(self, u, x, out, training, res=None):
         """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87)"""
         if not training:
             # eval(): BatchNorm folded into the weights (pack_weights(folded=True)) and an epilogue bias: one launch
-            ops.conv_bias_act_fwd(x, u.wf, u.ss[1], out, _ACT[u.act or res is not None], u.k, u.s, res=res)
+            self.o.conv_bias_act_fwd(x, u.wf, u.ss[1], out, _ACT[u.act or res is not None], u.k, u.s, res=res)
             return
-        ops.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles)
+        self.o.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles)
         self._bn_fwd(u, out, res)
 
     def _dgrad(self, u, dy, g_in, g_in_res=None, nxt=None):
         """g_in = data gradient of unit ``u`` [+ g_in_res].  ``nxt`` = (unit, its residual input or None) when
         g_in is, after this launch, the complete output gradient of that unit: the launch then also writes
-        the partial sums of that unit's BatchNorm backward (ops.conv_dgrad(bn=...)), which its _conv_bwd
+        the partial sums of that unit's BatchNorm backward (self.o.conv_dgrad(bn=...)), which its _conv_bwd
         -- always the next one to use bn_part -- consumes instead of running its own reduce pass."""
         if nxt is None or not self.fuse_bn_bwd or not nxt[0].bn:
-            ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s)
+            self.o.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s)
             return
         n, nres = nxt
         assert n.cout == u.cin and n.raw.shape == g_in.shape
-        ops.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s,
+        self.o.conv_dgrad(dy, u.wd, g_in, g_in_res, u.k, u.s,
                        bn=(n.raw, nres, n.ss, n.mr, _ACT[n.act or nres is not None], self.bn_part, u.dgrad_tiles))
         n.pre_rows = u.dgrad_tiles
 
@@ -344,26 +335,38 @@ class Engine:
         ``dres_accumulate`` is False.  ``nxt``: see _dgrad."""
         bn, dy = u.mod.bn, self._dy(u)
         rows, u.pre_rows = u.pre_rows, 0
-        ops.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
+        self.o.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
                        dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
                        partial_rows=rows)
-        ops.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
+        self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
         if g_in is not None:
             self._dgrad(u, dy, g_in, g_in_res, nxt)
 
     # ---------------------------------------------------------------- forward
-    @_in_plan_mode
+    def features_plain(self, feats):
+        """A feature / gradient tensor of this plan as plain numbers: split storage (compute_dtype "bf16x3") is joined into a
+        new fp32 tensor, the other modes return the tensor itself."""
+        return self.o.x3_join(feats) if self.x3 else feats
+
+    def set_plain(self, dst, src):
+        """dst (a buffer of this plan) = src given as plain numbers of dst's shape (split storage: split on the way in)."""
+        if self.x3:
+            self.o.x3_split(src.to(torch.float32).contiguous(), out=dst)
+        else:
+            dst.copy_(src)
+        return dst
+
     def backbone_forward(self, x, training=True):
-        """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512].
-        The packed weights must be current: pack_weights() before a training pass, fold_batchnorm() before an
-        inference pass (forward() does either)."""
+        """GELANNet.forward (model/gelan.py:165-176) on an NCHW fp32 batch; returns NHWC [B,h,w,512] in the plan's storage
+        (features_plain() gives plain numbers).  The packed weights must be current: pack_weights() before a training pass,
+        fold_batchnorm() before an inference pass (forward() does either)."""
         u1, bn1 = self.u_conv1, self.u_conv1.mod.bn
         self.x_in = x
         if training:
-            ops.conv1_stats(x, u1.wf, u1.stats)
-            ops.bn_finalize(u1.stats, u1.tiles, u1.M, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+            self.o.conv1_stats(x, u1.wf, u1.stats)
+            self.o.bn_finalize(u1.stats, u1.tiles, u1.M, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                             bn1.num_batches_tracked, u1.ss, u1.mr, bn1.momentum, bn1.eps)
-        ops.conv1_bn_act(x, u1.wf, u1.ss, self.a1, _ACT[u1.act])
+        self.o.conv1_bn_act(x, u1.wf, u1.ss, self.a1, _ACT[u1.act])
         self._conv(self.u_conv2, self.a1, self.a2, training)
         cur = self.a2
         for st in self.stages:
@@ -385,7 +388,6 @@ class Engine:
                 cur = st["dn"]
         return cur
 
-    @_in_plan_mode
     def forward(self, x, training=True, want_attn=True, refold=True):
         """MultiTaskNet.forward (model/multitasknet.py:24-29) -> (logits, heatmaps, attnmap).  ``refold=False``
         (eval only): the folded weights of the previous eval forward are still current (infer.InferenceSession)."""
@@ -396,50 +398,50 @@ class Engine:
             self.fold_batchnorm()
         feats = self.backbone_forward(x, training)
         up = self.u_proj
-        ops.conv_fwd(feats, up.wf, up.raw, None, 1, 1)                                   # multitasknet.py:26
+        self.o.conv_fwd(feats, up.wf, up.raw, None, 1, 1)                                   # multitasknet.py:26
         dec = self.model.decoder
-        ops.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                    # transformer.py:132-139
+        self.o.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                    # transformer.py:132-139
         B, N, D, Hh = self.B, self.N, self.dim, self.heads
         Mt = B * N
         for i, L in enumerate(self.layers):
             x0, x1, x2 = self.x[2 * i].view(Mt, D), self.x[2 * i + 1].view(Mt, D), self.x[2 * i + 2].view(Mt, D)
             at, ff = L["attn"], L["ff"]
-            ops.layernorm_fwd(x0, at.norm.weight, at.norm.bias, L["xn"], L["mr1"], at.norm.eps)
-            ops.linear_fwd(L["xn"], L["qkv_wf"], L["qkvb"])
+            self.o.layernorm_fwd(x0, at.norm.weight, at.norm.bias, L["xn"], L["mr1"], at.norm.eps)
+            self.o.linear_fwd(L["xn"], L["qkv_wf"], L["qkvb"])
             last = i == len(self.layers) - 1
-            ops.attention_fwd(L["qkvb"], L["ao"], L["lse"], self.attn if (last and want_attn) else None,
+            self.o.attention_fwd(L["qkvb"], L["ao"], L["lse"], self.attn if (last and want_attn) else None,
                               B, N, Hh, self.hd, at.scale)
-            ops.linear_fwd(L["ao"], L["out_wf"], x1, res=x0)                             # x = attn(x) + x
+            self.o.linear_fwd(L["ao"], L["out_wf"], x1, res=x0)                             # x = attn(x) + x
             ln = ff.net[0]
-            ops.layernorm_fwd(x1, ln.weight, ln.bias, L["xn2"], L["mr2"], ln.eps)
-            ops.linear_fwd(L["xn2"], L["fc1_wf"], L["hg"], bias=ff.net[1].bias, act=ops.ACT_GELU, aux_out=L["a"])
-            ops.linear_fwd(L["hg"], L["fc2_wf"], x2, bias=ff.net[4].bias, res=x1)       # x = ff(x) + x
+            self.o.layernorm_fwd(x1, ln.weight, ln.bias, L["xn2"], L["mr2"], ln.eps)
+            self.o.linear_fwd(L["xn2"], L["fc1_wf"], L["hg"], bias=ff.net[1].bias, act=self.o.ACT_GELU, aux_out=L["a"])
+            self.o.linear_fwd(L["hg"], L["fc2_wf"], x2, bias=ff.net[4].bias, res=x1)       # x = ff(x) + x
         xl = self.x[-1]
         head = dec.mlp_head
-        ops.cls_head_fwd(xl, head[0].weight, head[0].bias, head[1].weight, head[1].bias, self.logits,
+        self.o.cls_head_fwd(xl, head[0].weight, head[0].bias, head[1].weight, head[1].bias, self.logits,
                          self.cls_xhat, self.cls_mr, head[0].eps)
         pw = dec.simple_decoder[1]
-        ops.pose_head_fwd(xl, pw.weight, pw.bias, self.hm, self.fh, self.fw)
+        if self.x3:
+            self.o.x3_join(xl, out=self.xl_plain)
+        self.o.pose_head_fwd(self.xl_plain if self.x3 else xl, pw.weight, pw.bias, self.hm, self.fh, self.fw)
         return self.logits, self.hm, (self.attn if want_attn else None)
 
     # ---------------------------------------------------------------- loss
-    @_in_plan_mode
     def loss(self, label, target, target_weight, with_grads=True):
         """total = 0.001*CE + JointsMSE (train.py:63-64,75); fills dlogits/dhm when with_grads.
         The batch tensors follow libs/load.py (label int64 [B], target f32 [B,J,H/4,W/4],
         target_weight f32 [B,J,1]); float tensors of another float dtype are converted, anything
-        else (integer labels that are not int64, wrong shapes) raises in ops.loss_fwd_bwd."""
+        else (integer labels that are not int64, wrong shapes) raises in self.o.loss_fwd_bwd."""
         if target.dtype != torch.float32 and target.is_floating_point():
             target = target.float()
         if target_weight.dtype != torch.float32 and target_weight.is_floating_point():
             target_weight = target_weight.float()
-        ops.loss_fwd_bwd(self.logits, label.contiguous(), self.hm, target.contiguous(), target_weight.contiguous(),
+        self.o.loss_fwd_bwd(self.logits, label.contiguous(), self.hm, target.contiguous(), target_weight.contiguous(),
                          self.dlogits if with_grads else None, self.dhm if with_grads else None,
                          self.loss_part, self.losses)
         return self.losses
 
     # ---------------------------------------------------------------- backward
-    @_in_plan_mode
     def backbone_backward(self, g_feats):
         """Backward of backbone_forward given the gradient of its NHWC output (written into g buffers)."""
         for st in self.stages:          # (entered directly: no hand-over can be pending for the backbone's units except the
@@ -489,11 +491,10 @@ class Engine:
             self._ready(("stage", self.stages.index(st)))
         self._conv_bwd(self.u_conv2, self.g_a2, self.a1, self.g_a1)
         u1, bn = self.u_conv1, self.u_conv1.mod.bn
-        ops.conv1_bwd(self.x_in, u1.wf, self.g_a1, u1.ss, u1.mr, self.conv1_part, self._g(bn.weight), self._g(bn.bias),
+        self.o.conv1_bwd(self.x_in, u1.wf, self.g_a1, u1.ss, u1.mr, self.conv1_part, self._g(bn.weight), self._g(bn.bias),
                       self._g(u1.weight), _ACT[u1.act])
         self._ready("stem")
 
-    @_in_plan_mode
     def backward(self, dlogits=None, dhm=None):
         """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
         self.check_current()
@@ -507,9 +508,15 @@ class Engine:
         G, Gm = self.G, self.G.view(Mt, D)
         head, pw = dec.mlp_head, dec.simple_decoder[1]
         xl = self.x[-1]
-        ops.cls_head_bwd(dlogits, head[1].weight, head[0].weight, head[0].bias, self.cls_xhat, self.cls_mr, G,
-                         g(head[1].weight), g(head[1].bias), self._pair(head[0].weight, head[0].bias), self.cls_part)
-        ops.pose_head_bwd(xl, pw.weight, dhm, G, self._pair(pw.weight, pw.bias), self.pose_slab, self.fh, self.fw)
+        # (the pose head writes the patch-token rows of G, the classification head the class-token rows: split storage takes
+        #  the former through a plain copy that is split into G before the latter lands)
+        if self.x3:
+            self.o.pose_head_bwd(self.xl_plain, pw.weight, dhm, self.G_plain, self._pair(pw.weight, pw.bias), self.pose_slab, self.fh, self.fw)
+            self.o.x3_split(self.G_plain, out=G)
+        else:
+            self.o.pose_head_bwd(xl, pw.weight, dhm, G, self._pair(pw.weight, pw.bias), self.pose_slab, self.fh, self.fw)
+        self.o.cls_head_bwd(dlogits, head[1].weight, head[0].weight, head[0].bias, self.cls_xhat, self.cls_mr, G,
+                            g(head[1].weight), g(head[1].bias), self._pair(head[0].weight, head[0].bias), self.cls_part)
         for i in reversed(range(len(self.layers))):
             L = self.layers[i]
             x0, x1 = self.x[2 * i].view(Mt, D), self.x[2 * i + 1].view(Mt, D)
@@ -518,34 +525,34 @@ class Engine:
             # x2 = fc2(gelu(fc1(LN(x1)))) + x1
             defer = self.leaf_plan is not None
             if defer:
-                ops.bias_grad(Gm, L["p_b2"], None)
+                self.o.bias_grad(Gm, L["p_b2"], None)
             else:
-                ops.bias_grad(Gm, self.row_part, g(fc2.bias))
-            ops.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
+                self.o.bias_grad(Gm, self.row_part, g(fc2.bias))
+            self.o.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
             if self.fuse_gelu_bwd:
                 # d a = (G @ fc2.W) * gelu'(a) and fc1's bias gradient (its column sums) in one launch
-                ops.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
+                self.o.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
                                     None if defer else g(fc1.bias))
             else:
-                ops.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
-                ops.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
-                ops.bias_grad(self.t_b, self.row_part, g(fc1.bias))
-            ops.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
-            ops.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
-            ops.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, L["p_ln2"] if defer else self.row_part,
+                self.o.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
+                self.o.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
+                self.o.bias_grad(self.t_b, self.row_part, g(fc1.bias))
+            self.o.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
+            self.o.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
+            self.o.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, L["p_ln2"] if defer else self.row_part,
                               None if defer else self._pair(ln2.weight, ln2.bias), dres=Gm)
             # x1 = to_out(attention(LN(x0))) + x0
-            ops.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
-            ops.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
-            ops.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
-            ops.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
-            ops.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
-            ops.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
+            self.o.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
+            self.o.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
+            self.o.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
+            self.o.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
+            self.o.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
+            self.o.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
                               None if defer else self._pair(at.norm.weight, at.norm.bias), dres=Gm)
-        ops.tokens_bwd(G, self.g_feat, g(dec.cls_token))
+        self.o.tokens_bwd(G, self.g_feat, g(dec.cls_token))
         up, last = self.u_proj, self.stages[-1]
         gf = self.g_feat.view(self.B, self.fh, self.fw, D)
-        ops.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
+        self.o.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
         self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
         if self.leaf_plan is not None:
             self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches

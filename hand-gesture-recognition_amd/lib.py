@@ -68,6 +68,7 @@ _PROTOS = {
     "mtn_adamw_step": [_vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "mtn_pack_weights": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_conv_bias_act_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mtn_x3_convert": [_vp, _i, _vp, _i, _i, _ll, _i, _vp],
     "mtn_heatmap_argmax": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_pose_accuracy": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mtn_cls_confusion": [_vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -84,7 +85,7 @@ _STATUS_FREE = {"mtn_abi_version", "mtn_colsum_rows_per_block", "mtn_colsum_dire
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",
                 "mtn_loss_partial_len"}   # return a value, not a status
 
-EXPECTED_ABI = 4          # include/mtn.h MTN_ABI_VERSION these prototypes were written for
+EXPECTED_ABI = 5          # include/mtn.h MTN_ABI_VERSION these prototypes were written for
 
 _lib = None
 _lib_path = None

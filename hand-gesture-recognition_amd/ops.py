@@ -11,9 +11,11 @@ from . import lib
 F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
-# How fp32 tensors are multiplied by the GEMM-shaped kernels: F32 = exact-f32 MFMA, F32X3 = split-bf16
-# (three bf16 MFMAs per product; include/mtn.h MTN_DTYPE_F32X3).  Storage is fp32 either way, so the
-# choice cannot be read off a tensor: the execution plan (Engine) selects it before it launches.
+# What a torch.float32 tensor holds: F32 = plain fp32 (exact-f32 MFMA) or F32X3 = split storage (bf16 hi / lo halves per
+# 32-channel block, three bf16 MFMAs per product; include/mtn.h MTN_DTYPE_F32X3).  It cannot be read off the tensor, so every
+# wrapper takes it per call (``mode=``), like the C ABI takes its dtype argument: an execution plan passes its own
+# (``with_mode``), two plans of different modes can run from different threads.  ``_f32_code`` is only the DEFAULT for direct
+# callers that pass nothing (kernel tests select it with set_f32_matmul); the package itself never relies on it.
 _f32_code = F32
 
 
@@ -24,16 +26,41 @@ def set_f32_matmul(code):
     _f32_code = code
 
 
-def code_of(dtype):
+def code_of(dtype, mode=None):
     if dtype == torch.bfloat16:
         return BF16
     if dtype == torch.float32:
-        return _f32_code
+        if mode is None:
+            return _f32_code
+        if mode not in (F32, F32X3):
+            raise ValueError(f"fp32 mode {mode}")
+        return mode
     raise TypeError(f"unsupported storage dtype {dtype}")
 
 
-def dtype_code(t):
-    return code_of(t.dtype)
+def dtype_code(t, mode=None):
+    return code_of(t.dtype, mode)
+
+
+class with_mode:
+    """The wrappers of this module with ``mode`` bound: ``o = ops.with_mode(ops.F32X3); o.conv_fwd(...)`` calls
+    ``ops.conv_fwd(..., mode=ops.F32X3)``.  Names are resolved on the module at CALL time (a wrapper that instruments or
+    replaces ``ops.conv_fwd`` -- bench.py's roofline brackets, tests -- is honoured and receives ``mode=`` like the function
+    it stands in for); names that take no mode (constants, size queries without a dtype) pass through."""
+
+    def __init__(self, mode):
+        import sys
+        if mode not in (F32, F32X3):
+            raise ValueError(f"fp32 mode {mode}")
+        self.mode = mode
+        self._mod = sys.modules[__name__]
+
+    def __getattr__(self, name):
+        fn = getattr(self._mod, name)
+        if name in _MODED:
+            import functools
+            return functools.partial(fn, mode=self.mode)
+        return fn
 
 
 def _stream(t):
@@ -60,12 +87,12 @@ def conv_stats_tiles(M, cout, K):
     return lib.call("mtn_conv_stats_tiles", M, cout, K)
 
 
-def conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
+def conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
     """rows of the partial-statistics slab conv_fwd writes for this layer geometry."""
-    return lib.call("mtn_conv_fwd_stats_tiles", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
+    return lib.call("mtn_conv_fwd_stats_tiles", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
-def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
+def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None, mode=None):
     """x [B,H,W,Cin] -> y [B,OH,OW,Cout] raw conv output; stats [>=tiles,2,Cout] f32 or None
     (tiles = conv_fwd_stats_tiles(...): the slab is allocated with slab_rows(tiles) rows)."""
     B, H, W, Cin = x.shape
@@ -76,14 +103,14 @@ def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None):
     if stats is not None:
         # the row count the slab was SIZED for (a plan passes what it allocated; the library refuses
         # the launch if its tile choice no longer matches)
-        tiles = conv_fwd_stats_tiles(x.dtype, B, H, W, Cin, Cout, ksize, stride) if stats_tiles is None else int(stats_tiles)
+        tiles = conv_fwd_stats_tiles(x.dtype, B, H, W, Cin, Cout, ksize, stride, mode=mode) if stats_tiles is None else int(stats_tiles)
         if stats.dtype != torch.float32 or stats.numel() < tiles * 2 * Cout:
             raise ValueError(f"conv_fwd: stats slab too small for {tiles} row tiles")
-    lib.call("mtn_conv_fwd", xp, ldx, w.data_ptr(), yp, ldy, _p(stats), tiles, dtype_code(x),
+    lib.call("mtn_conv_fwd", xp, ldx, w.data_ptr(), yp, ldy, _p(stats), tiles, dtype_code(x, mode),
              B, H, W, Cin, Cout, ksize, stride, _stream(x))
 
 
-def conv_bias_act_fwd(x, w, bias, y, act, ksize, stride, res=None):
+def conv_bias_act_fwd(x, w, bias, y, act, ksize, stride, res=None, mode=None):
     """Inference form of a Conv unit with folded BatchNorm: y = act(conv(x) + bias [+ res]) in one launch
     (w = weights packed with the BatchNorm scale, bias f32 [Cout] = its shift)."""
     B, H, W, Cin = x.shape
@@ -93,15 +120,15 @@ def conv_bias_act_fwd(x, w, bias, y, act, ksize, stride, res=None):
     xp, ldx = _rows(x)
     yp, ldy = _rows(y)
     rp, ldr = _rows(res) if res is not None else (0, 0)
-    lib.call("mtn_conv_bias_act_fwd", xp, ldx, w.data_ptr(), bias.data_ptr(), act, rp, ldr, yp, ldy, dtype_code(x),
+    lib.call("mtn_conv_bias_act_fwd", xp, ldx, w.data_ptr(), bias.data_ptr(), act, rp, ldr, yp, ldy, dtype_code(x, mode),
              B, H, W, Cin, Cout, ksize, stride, _stream(x))
 
 
-def conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, ksize, stride):
-    return lib.call("mtn_conv_dgrad_bn_tiles", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
+def conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
+    return lib.call("mtn_conv_dgrad_bn_tiles", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
-def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None):
+def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None, mode=None):
     """dy [B,OH,OW,Cout] -> dx [B,H,W,Cin] (+ res, which may alias dx).
 
     ``bn`` = (y, res, scale_shift, mean_rstd, act, partial, tiles) of the Conv unit whose output gradient dx is: the
@@ -112,7 +139,7 @@ def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None):
     dxp, lddx = _rows(dx)
     rp, ldr = _rows(res) if res is not None else (0, 0)
     if bn is None:
-        lib.call("mtn_conv_dgrad", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, dtype_code(dy),
+        lib.call("mtn_conv_dgrad", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, dtype_code(dy, mode),
                  B, H, W, Cin, Cout, ksize, stride, _stream(dy))
         return
     y, bres, ss, mr, act, partial, tiles = bn
@@ -123,10 +150,10 @@ def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None):
     yp, ldy = _rows(y)
     brp, ldbr = _rows(bres) if bres is not None else (0, 0)
     lib.call("mtn_conv_dgrad_bn", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, yp, ldy, brp, ldbr, ss.data_ptr(),
-             mr.data_ptr(), act, partial.data_ptr(), tiles, dtype_code(dy), B, H, W, Cin, Cout, ksize, stride, _stream(dy))
+             mr.data_ptr(), act, partial.data_ptr(), tiles, dtype_code(dy, mode), B, H, W, Cin, Cout, ksize, stride, _stream(dy))
 
 
-def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None):
+def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None, mode=None):
     """out = act(x @ w.T + bias) + res; x [M,K] rows, w [N,K]."""
     K = x.shape[-1]
     N = out.shape[-1]
@@ -136,14 +163,14 @@ def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None):
     ap, lda = _rows(aux_out) if aux_out is not None else (0, 0)
     rp, ldr = _rows(res) if res is not None else (0, 0)
     lib.call("mtn_linear_fwd", xp, ldx, w.data_ptr(), _p(bias), act, ap, lda, rp, ldr, op, ldo,
-             dtype_code(x), M, N, K, _stream(x))
+             dtype_code(x, mode), M, N, K, _stream(x))
 
 
 def linear_gelu_bwd_tiles(M, N, K):
     return lib.call("mtn_linear_gelu_bwd_tiles", M, N, K)
 
 
-def linear_gelu_bwd(dh, wt, a, da, partial, tiles, dbias):
+def linear_gelu_bwd(dh, wt, a, da, partial, tiles, dbias, mode=None):
     """da = (dh @ wt.T) * gelu'(a); dbias = column sums of da (f32 [N], overwritten).  dh [M,K], wt [N,K], a / da [M,N]."""
     K, N = dh.shape[-1], da.shape[-1]
     M = dh.numel() // K
@@ -157,14 +184,14 @@ def linear_gelu_bwd(dh, wt, a, da, partial, tiles, dbias):
     ap, lda = _rows(a)
     dp, ldd = _rows(da)
     lib.call("mtn_linear_gelu_bwd", hp, ldh, wt.data_ptr(), ap, lda, dp, ldd, partial.data_ptr(), tiles, _p(dbias),
-             dtype_code(dh), M, N, K, _stream(dh))
+             dtype_code(dh, mode), M, N, K, _stream(dh))
 
 
-def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride):
-    return lib.call("mtn_conv_wgrad_workspace_bytes", code_of(dtype), B, H, W, Cin, Cout, ksize, stride)
+def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
+    return lib.call("mtn_conv_wgrad_workspace_bytes", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
-def conv_wgrad(x, dy, dw, workspace, ksize, stride):
+def conv_wgrad(x, dy, dw, workspace, ksize, stride, mode=None):
     """x [B,H,W,Cin], dy [B,OH,OW,Cout] -> dw f32 [Cout,Cin,k,k] (overwritten)."""
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -172,22 +199,22 @@ def conv_wgrad(x, dy, dw, workspace, ksize, stride):
     dyp, lddy = _rows(dy)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     lib.call("mtn_conv_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
-             workspace.numel() * workspace.element_size(), dtype_code(x), B, H, W, Cin, Cout,
+             workspace.numel() * workspace.element_size(), dtype_code(x, mode), B, H, W, Cin, Cout,
              ksize, stride, _stream(x))
 
 
-def linear_wgrad_workspace_bytes(dtype, M, N, K):
-    return lib.call("mtn_linear_wgrad_workspace_bytes", code_of(dtype), M, N, K)
+def linear_wgrad_workspace_bytes(dtype, M, N, K, mode=None):
+    return lib.call("mtn_linear_wgrad_workspace_bytes", code_of(dtype, mode), M, N, K)
 
 
-def linear_wgrad(x, dy, dw, workspace):
+def linear_wgrad(x, dy, dw, workspace, mode=None):
     """dw[N,K] = dy[M,N]^T @ x[M,K] (f32, overwritten)."""
     K, N = x.shape[-1], dy.shape[-1]
     M = x.numel() // K
     xp, ldx = _rows(x)
     dyp, lddy = _rows(dy)
     lib.call("mtn_linear_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
-             workspace.numel() * workspace.element_size(), dtype_code(x), M, N, K, _stream(x))
+             workspace.numel() * workspace.element_size(), dtype_code(x, mode), M, N, K, _stream(x))
 
 
 def slab_rows(rows):
@@ -207,13 +234,13 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, scale_shift, eps
              running_var.data_ptr(), eps, scale_shift.data_ptr(), gamma.numel(), _stream(gamma))
 
 
-def bn_act_fwd(y, scale_shift, out, act, res=None):
+def bn_act_fwd(y, scale_shift, out, act, res=None, mode=None):
     C = y.shape[-1]
     M = y.numel() // C
     yp, ldy = _rows(y)
     op, ldo = _rows(out)
     rp, ldr = _rows(res) if res is not None else (0, 0)
-    lib.call("mtn_bn_act_fwd", yp, ldy, scale_shift.data_ptr(), rp, ldr, op, ldo, dtype_code(y),
+    lib.call("mtn_bn_act_fwd", yp, ldy, scale_shift.data_ptr(), rp, ldr, op, ldo, dtype_code(y, mode),
              M, C, act, _stream(y))
 
 
@@ -222,7 +249,7 @@ def bn_bwd_partial_rows(M):
 
 
 def bn_act_bwd(dout, y, res, scale_shift, mean_rstd, partial, coef, dgamma, dbeta, dy, act,
-               dres=None, extra=None, partial_rows=0):
+               dres=None, extra=None, partial_rows=0, mode=None):
     C = y.shape[-1]
     M = y.numel() // C
     dop, lddo = _rows(dout)
@@ -233,54 +260,54 @@ def bn_act_bwd(dout, y, res, scale_shift, mean_rstd, partial, coef, dgamma, dbet
     ep, lde = _rows(extra) if extra is not None else (0, 0)
     lib.call("mtn_bn_act_bwd", dop, lddo, yp, ldy, rp, ldr, scale_shift.data_ptr(),
              mean_rstd.data_ptr(), partial.data_ptr(), coef.data_ptr(), dgamma.data_ptr(),
-             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, partial_rows, dtype_code(y), M, C, act, _stream(y))
+             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, partial_rows, dtype_code(y, mode), M, C, act, _stream(y))
 
 
 def conv1_stats_tiles(B, H, W):
     return lib.call("mtn_conv1_stats_tiles", B, H, W)
 
 
-def conv1_fwd(x_nchw, w, y, stats):
+def conv1_fwd(x_nchw, w, y, stats, mode=None):
     """x f32 [B,3,H,W] (NCHW, as the dataloader delivers it) -> y [B,H/2,W/2,64] raw."""
     B, _, H, W = x_nchw.shape
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and y.is_contiguous()
     lib.call("mtn_conv1_fwd", x_nchw.data_ptr(), w.data_ptr(), y.data_ptr(), _p(stats),
-             dtype_code(y), B, H, W, _stream(y))
+             dtype_code(y, mode), B, H, W, _stream(y))
 
 
 def conv1_wgrad_partial_rows(B, H, W):
     return lib.call("mtn_conv1_wgrad_partial_rows", B, H, W)
 
 
-def conv1_wgrad(x_nchw, dy, dw, partial):
+def conv1_wgrad(x_nchw, dy, dw, partial, mode=None):
     B, _, H, W = x_nchw.shape
     assert dy.is_contiguous() and dw.is_contiguous()
     lib.call("mtn_conv1_wgrad", x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), partial.data_ptr(),
-             dtype_code(dy), B, H, W, _stream(dy))
+             dtype_code(dy, mode), B, H, W, _stream(dy))
 
 
-def conv1_stats(x_nchw, w, stats):
+def conv1_stats(x_nchw, w, stats, mode=None):
     """fused stem, pass 1: BN partial statistics of conv(x) (nothing else is stored)."""
     B, _, H, W = x_nchw.shape
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and stats.dtype == torch.float32
     assert stats.numel() >= conv1_stats_tiles(B, H, W) * 128
-    lib.call("mtn_conv1_stats", x_nchw.data_ptr(), w.data_ptr(), stats.data_ptr(), dtype_code(w), B, H, W, _stream(stats))
+    lib.call("mtn_conv1_stats", x_nchw.data_ptr(), w.data_ptr(), stats.data_ptr(), dtype_code(w, mode), B, H, W, _stream(stats))
 
 
-def conv1_bn_act(x_nchw, w, scale_shift, out, act):
+def conv1_bn_act(x_nchw, w, scale_shift, out, act, mode=None):
     """fused stem, pass 2: out [B,H/2,W/2,64] = act(conv(x) * scale + shift)."""
     B, _, H, W = x_nchw.shape
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and out.is_contiguous()
     assert tuple(out.shape) == (B, H // 2, W // 2, 64) and out.dtype == w.dtype
     lib.call("mtn_conv1_bn_act", x_nchw.data_ptr(), w.data_ptr(), scale_shift.data_ptr(), out.data_ptr(), act,
-             dtype_code(out), B, H, W, _stream(out))
+             dtype_code(out, mode), B, H, W, _stream(out))
 
 
 def conv1_bwd_partial_shape(B, H, W):
     return lib.call("mtn_conv1_bwd_partial_rows", B, H, W), lib.call("mtn_conv1_bwd_partial_width")
 
 
-def conv1_bwd(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, dw, act):
+def conv1_bwd(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, dw, act, mode=None):
     """fused stem backward: dgamma, dbeta [64] and dw f32 [64,3,3,3] from (x, d activation) in one pass."""
     B, _, H, W = x_nchw.shape
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and dout.is_contiguous() and dw.is_contiguous()
@@ -289,54 +316,54 @@ def conv1_bwd(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, d
     assert partial.dtype == torch.float32 and partial.numel() >= rows * width
     lib.call("mtn_conv1_bwd", x_nchw.data_ptr(), w.data_ptr(), dout.data_ptr(), scale_shift.data_ptr(),
              mean_rstd.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dw.data_ptr(), act,
-             dtype_code(dout), B, H, W, _stream(dout))
+             dtype_code(dout, mode), B, H, W, _stream(dout))
 
 
 # ---- ViT encoder --------------------------------------------------------------------------------
-def tokens_fwd(feat, pos, cls, tok):
+def tokens_fwd(feat, pos, cls, tok, mode=None):
     """feat [B*P,256] (+pos f32 [P,256]) and cls f32 [256] -> tok [B,P+1,256]."""
     B, P1, _ = tok.shape
     lib.call("mtn_tokens_fwd", feat.data_ptr(), pos.data_ptr(), cls.data_ptr(), tok.data_ptr(),
-             dtype_code(tok), B, P1 - 1, _stream(tok))
+             dtype_code(tok, mode), B, P1 - 1, _stream(tok))
 
 
-def tokens_bwd(dtok, dfeat, dcls):
+def tokens_bwd(dtok, dfeat, dcls, mode=None):
     B, P1, _ = dtok.shape
-    lib.call("mtn_tokens_bwd", dtok.data_ptr(), dfeat.data_ptr(), dcls.data_ptr(), dtype_code(dtok),
+    lib.call("mtn_tokens_bwd", dtok.data_ptr(), dfeat.data_ptr(), dcls.data_ptr(), dtype_code(dtok, mode),
              B, P1 - 1, _stream(dtok))
 
 
-def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5):
+def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5, mode=None):
     xp, ldx = _rows(x)
     yp, ldy = _rows(y)
     M = x.numel() // x.shape[-1]
     lib.call("mtn_layernorm_fwd", xp, ldx, gamma.data_ptr(), beta.data_ptr(), yp, ldy, _p(mean_rstd),
-             dtype_code(x), M, eps, _stream(x))
+             dtype_code(x, mode), M, eps, _stream(x))
 
 
 def rowslab_rows(M):
     return lib.call("mtn_rowslab_rows", M)
 
 
-def layernorm_bwd(dy, x, mean_rstd, gamma, dx, partial, dgamma_dbeta, dres=None):
+def layernorm_bwd(dy, x, mean_rstd, gamma, dx, partial, dgamma_dbeta, dres=None, mode=None):
     dyp, lddy = _rows(dy)
     xp, ldx = _rows(x)
     dxp, lddx = _rows(dx)
     rp, ldr = _rows(dres) if dres is not None else (0, 0)
     M = x.numel() // x.shape[-1]
     lib.call("mtn_layernorm_bwd", dyp, lddy, xp, ldx, mean_rstd.data_ptr(), gamma.data_ptr(), rp, ldr,
-             dxp, lddx, partial.data_ptr(), _p(dgamma_dbeta), dtype_code(x), M, _stream(x))
+             dxp, lddx, partial.data_ptr(), _p(dgamma_dbeta), dtype_code(x, mode), M, _stream(x))
 
 
-def gelu_bwd(dh, a, da):
+def gelu_bwd(dh, a, da, mode=None):
     assert dh.is_contiguous() and a.is_contiguous() and da.is_contiguous()
-    lib.call("mtn_gelu_bwd", dh.data_ptr(), a.data_ptr(), da.data_ptr(), dtype_code(a), a.numel(), _stream(a))
+    lib.call("mtn_gelu_bwd", dh.data_ptr(), a.data_ptr(), da.data_ptr(), dtype_code(a, mode), a.numel(), _stream(a))
 
 
-def bias_grad(dy, partial, dbias):
+def bias_grad(dy, partial, dbias, mode=None):
     dyp, lddy = _rows(dy)
     M = dy.numel() // dy.shape[-1]
-    lib.call("mtn_bias_grad", dyp, lddy, partial.data_ptr(), _p(dbias), dtype_code(dy), M, _stream(dy))
+    lib.call("mtn_bias_grad", dyp, lddy, partial.data_ptr(), _p(dbias), dtype_code(dy, mode), M, _stream(dy))
 
 
 def rowslab_producer_rows(M):
@@ -383,41 +410,41 @@ class ColsumPlan:
                  _stream(self.t2))
 
 
-def attention_fwd(qkv, out, lse, attn, B, N, H, D, scale):
+def attention_fwd(qkv, out, lse, attn, B, N, H, D, scale, mode=None):
     lib.call("mtn_attention_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(attn),
-             dtype_code(qkv), B, N, H, D, scale, _stream(qkv))
+             dtype_code(qkv, mode), B, N, H, D, scale, _stream(qkv))
 
 
-def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, mode=None):
     lib.call("mtn_attention_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-             delta.data_ptr(), dqkv.data_ptr(), dtype_code(qkv), B, N, H, D, scale, _stream(qkv))
+             delta.data_ptr(), dqkv.data_ptr(), dtype_code(qkv, mode), B, N, H, D, scale, _stream(qkv))
 
 
-def cls_head_fwd(tok, ln_w, ln_b, W, bias, logits, xhat, mean_rstd, eps=1e-5):
+def cls_head_fwd(tok, ln_w, ln_b, W, bias, logits, xhat, mean_rstd, eps=1e-5, mode=None):
     B, C = logits.shape
     lib.call("mtn_cls_head_fwd", tok.data_ptr(), tok.stride(0), ln_w.data_ptr(), ln_b.data_ptr(),
              W.data_ptr(), bias.data_ptr(), logits.data_ptr(), xhat.data_ptr(), mean_rstd.data_ptr(),
-             dtype_code(tok), B, C, eps, _stream(tok))
+             dtype_code(tok, mode), B, C, eps, _stream(tok))
 
 
-def cls_head_bwd(dlogits, W, ln_w, ln_b, xhat, mean_rstd, dtok, dW, dbias, dln_w_b, partial):
+def cls_head_bwd(dlogits, W, ln_w, ln_b, xhat, mean_rstd, dtok, dW, dbias, dln_w_b, partial, mode=None):
     B, C = dlogits.shape
     lib.call("mtn_cls_head_bwd", dlogits.data_ptr(), W.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
              xhat.data_ptr(), mean_rstd.data_ptr(), dtok.data_ptr(), dtok.stride(0), dW.data_ptr(),
-             dbias.data_ptr(), dln_w_b.data_ptr(), partial.data_ptr(), dtype_code(dtok), B, C, _stream(dtok))
+             dbias.data_ptr(), dln_w_b.data_ptr(), partial.data_ptr(), dtype_code(dtok, mode), B, C, _stream(dtok))
 
 
-def pose_head_fwd(tok, W, bias, hm, h, w):
+def pose_head_fwd(tok, W, bias, hm, h, w, mode=None):
     B, J = hm.shape[:2]
     lib.call("mtn_pose_head_fwd", tok.data_ptr(), W.data_ptr(), bias.data_ptr(), hm.data_ptr(),
-             dtype_code(tok), B, h, w, J, _stream(tok))
+             dtype_code(tok, mode), B, h, w, J, _stream(tok))
 
 
-def pose_head_bwd(tok, W, dhm, dtok, dW_dbias, slab, h, w):
+def pose_head_bwd(tok, W, dhm, dtok, dW_dbias, slab, h, w, mode=None):
     """dW_dbias: f32 [J*256 + J] = weight gradient followed by the bias gradient."""
     B, J = dhm.shape[:2]
     lib.call("mtn_pose_head_bwd", tok.data_ptr(), W.data_ptr(), dhm.data_ptr(), dtok.data_ptr(),
-             dW_dbias.data_ptr(), slab.data_ptr(), dtype_code(tok), B, h, w, J, _stream(tok))
+             dW_dbias.data_ptr(), slab.data_ptr(), dtype_code(tok, mode), B, h, w, J, _stream(tok))
 
 
 def loss_partial_len(n):
@@ -467,9 +494,41 @@ def adamw_step(p, g, m, v, state):
              state.data_ptr(), _stream(p))
 
 
-def pack_weights(src, dst, desc, ntensors, max_elems, scale=None):
+def x3_convert(src, dst, to_split):
+    """split storage <-> plain f32 (include/mtn.h mtn_x3_convert): src / dst f32 [..., C] row tensors of one shape; the split
+    side holds, per 32-channel block, [32 bf16 hi][32 bf16 lo]."""
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or src.shape != dst.shape:
+        raise ValueError("x3_convert: two f32 tensors of one shape")
+    C = src.shape[-1]
+    sp, lds = _rows(src)
+    dp, ldd = _rows(dst)
+    lib.call("mtn_x3_convert", sp, lds, dp, ldd, 1 if to_split else 0, src.numel() // C, C, _stream(src))
+    return dst
+
+
+def x3_split(t, out=None):
+    """plain f32 -> split storage (new tensor unless ``out``)"""
+    return x3_convert(t, torch.empty_like(t) if out is None else out, True)
+
+
+def x3_join(t, out=None):
+    """split storage -> plain f32"""
+    return x3_convert(t, torch.empty_like(t) if out is None else out, False)
+
+
+def pack_weights(src, dst, desc, ntensors, max_elems, scale=None, mode=None):
     """desc int32 [ntensors][7] (include/mtn.h); ``scale``: f32 buffer the rows' scale_off index into."""
     if desc.dtype != torch.int32 or desc.numel() != ntensors * 7:
         raise ValueError("pack_weights: desc must be int32 [ntensors][7]")
     lib.call("mtn_pack_weights", src.data_ptr(), _p(scale), dst.data_ptr(), desc.data_ptr(), ntensors, max_elems,
-             dtype_code(dst), _stream(dst))
+             dtype_code(dst, mode), _stream(dst))
+
+
+def _moded_names():
+    import inspect
+    import sys
+    return frozenset(name for name, fn in vars(sys.modules[__name__]).items()
+                     if inspect.isfunction(fn) and "mode" in inspect.signature(fn).parameters)
+
+
+_MODED = _moded_names()      # the wrappers that take ``mode`` (fixed at import: a later stand-in for one of them still gets it)

@@ -13,17 +13,25 @@
  *   - the caller (PyTorch) owns every buffer incl. workspaces (`*_workspace_bytes` sizes them).
  *   - dtype: MTN_DTYPE_F32 = fp32 storage + exact-f32 MFMA (validation mode),
  *            MTN_DTYPE_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation (throughput mode),
- *            MTN_DTYPE_F32X3 = fp32 storage exactly like MTN_DTYPE_F32; the GEMM-shaped entry points
- *            (mtn_conv_fwd / _dgrad / _dgrad_bn / _wgrad, mtn_linear_fwd / _gelu_bwd / _wgrad) split both
- *            operands into bf16 hi + lo in registers and multiply with three bf16 MFMAs per product
- *            (fp32 accumulate; ~2^-17 relative error per product) -- the 1e-3 tolerance of the reference's
- *            fp32 training (train.py:19,230: fp32 with TF32 matmuls allowed) at throughput.  Every other
- *            entry point treats it as MTN_DTYPE_F32.
+ *            MTN_DTYPE_F32X3 = SPLIT storage, 4 bytes per element (ABI 5): every 32-channel block of a row -- 128
+ *            bytes -- holds [32 bf16 hi][32 bf16 lo], hi = bf16_rne(x), lo = bf16_rne(x - hi), channels in natural
+ *            order (x = hi + lo to ~2^-17).  Every entry point that writes an activation / gradient tensor under
+ *            this dtype writes that layout (each element is split ONCE, by its producer), every one that reads
+ *            one expects it; the GEMM-shaped entry points (mtn_conv_fwd / _dgrad / _dgrad_bn / _wgrad,
+ *            mtn_linear_fwd / _gelu_bwd / _wgrad, mtn_attention_*) take their MFMA operands from it without any
+ *            conversion and multiply with three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32
+ *            accumulate; ~2^-17 relative error per product) -- the 1e-3 tolerance of the reference's fp32
+ *            training (train.py:19,230: fp32 with TF32 matmuls allowed) at throughput.  Tensors start on a 16-byte
+ *            boundary at a channel that is a multiple of 32; channel counts and row strides are multiples of 32.  mtn_x3_convert moves
+ *            a tensor between this layout and plain f32 (module boundary).  EXCEPTIONS, which take / write PLAIN
+ *            f32 under this dtype: the image, every f32-typed argument (statistics, parameters, logits,
+ *            heat-maps, attention map, lse), the unfused stem entries mtn_conv1_fwd / _wgrad, and the token
+ *            tensors of mtn_pose_head_fwd / _bwd (convert at that boundary).
  *     Statistics, gradients of parameters, optimizer state and losses are always fp32.
  *   - activations are NHWC ("channels last") / token-major [rows][channels]; `ld*` is the
  *     element stride between consecutive rows (pixels), so an op can read or write a channel
  *     slice of a wider buffer (this is how torch.cat / chunk of model/gelan.py:138,142 are free).
- *   - pointers and row strides must keep 16-byte alignment.
+ *   - pointers and row strides must keep 16-byte alignment (split storage: row strides of 32 elements, above).
  */
 #ifndef MTN_H_
 #define MTN_H_
@@ -263,12 +271,16 @@ int mtn_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
  * scale[scale_off + o] -- inference with BatchNorm folded into the convolution (the reference runs its
  * model in eval() for export / evaluation, export.py:41-45): scale = gamma / sqrt(running_var + eps) from
  * mtn_bn_eval_scale_shift, the matching shift goes to mtn_conv_bias_act_fwd as its bias.  -1: no factor.
- * dtype MTN_DTYPE_F32X3: the GEMM-shaped entry points expect their WEIGHT operand pre-split -- every 32-k block of a
- * packed row as [32 bf16 hi][32 bf16 lo] (the 128 bytes of the fp32 block, k order of the kernels' fragments) -- which is
- * what this function writes under that dtype; mode + 2 keeps a tensor in plain fp32 (the stem: mtn_conv1_* multiply in
- * exact f32).  Packed row lengths (I*taps for mode 0, O*taps for mode 1) must then be multiples of 32. */
+ * dtype MTN_DTYPE_F32X3: the packed weights are written in split storage like the activations -- every 32-k block of a
+ * packed row as [32 bf16 hi][32 bf16 lo], k in natural order; mode + 2 keeps a tensor in plain fp32 (the stem: mtn_conv1_*
+ * multiply in exact f32).  Packed row lengths (I*taps for mode 0, O*taps for mode 1) must then be multiples of 32. */
 int mtn_pack_weights(const float* src, const float* scale, void* dst, const int* desc, int ntensors,
                      int max_elems, int dtype, void* stream);
+
+/* split storage (MTN_DTYPE_F32X3) <-> plain f32: rows of C channels (C, ld_src, ld_dst multiples of 32; 16-byte aligned),
+ * to_split != 0: src plain f32 -> dst split; 0: src split -> dst plain f32.  Used where a split tensor crosses the module
+ * boundary (backbone features / their gradient) and around the pose head. */
+int mtn_x3_convert(const void* src, int ld_src, void* dst, int ld_dst, int to_split, long long M, int C, void* stream);
 
 /* ---- step metrics on the device (reference: host numpy / sklearn per step) ------
  * get_max_preds (libs/utils.py:4-32): preds f32 [maps][2] = (x, y) of the first maximum, zeroed
@@ -303,8 +315,8 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  * key 18 = kernel-row tiles of the 64-channel 3x3 weight gradient (0: one tap per tile);
  * key 3 = 7 / 8 and key 6 = 4 / 5 / 6: measured-and-rejected igemm pipelines kept for their tests (ping-pong wave
  *          halves, weights through registers, 256x128 tiles: DESIGN.md section 7d); keys 19 / 20: split-bf16 tile /
- *          LDS-stage variants; key 21 = stem backward on split-bf16 products.
- * Every key is refused (MTN_ERR_BAD_ARG, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
+ *          LDS-stage variants; key 21 = retired (accepted, no effect).
+ * Every key is refused (MTN_ERR_UNSUPPORTED, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
  * call into the library: the product path has no mutable configuration.
  * The environment variable MTN_DEBUG_KEYS="k=v,k=v" applies keys when the binding loads the library.
  * mtn_debug_read: key 1 = in-kernel phase stamps of the last igemm launch (diagnostic builds with

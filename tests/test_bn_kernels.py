@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import DTYPES, be, rel_err, tol  # noqa: F401
+from backend import DTYPES, GEMM_DTYPES, A, Fl, be, rel_err, tol  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
@@ -46,28 +46,28 @@ def test_bn_act_fwd_bwd(be, dtype, cfg):
     ss, mr = torch.empty(2, C, device=d), torch.empty(2, C, device=d)
     rmd, rvd = torch.zeros(C, device=d), torch.ones(C, device=d)
     nbt = torch.zeros((), dtype=torch.int64, device=d)
-    yd, gd, bd = y.to(d), gamma.to(d), beta.to(d)
-    resd = res.to(d) if with_res else None
+    yd, gd, bd = A(y).to(d), gamma.to(d), beta.to(d)
+    resd = A(res).to(d) if with_res else None
     ops.bn_finalize(stats, tiles, M, gd, bd, rmd, rvd, nbt, ss, mr)
     out = torch.empty((M, C), dtype=dtype, device=d)
     a = ops.ACT_SILU if act else ops.ACT_NONE
     ops.bn_act_fwd(yd, ss, out, a, resd)
     be.sync()
-    assert rel_err(out.float(), out_ref) < tol(dtype, 1e-4, 2e-2)
+    assert rel_err(Fl(out), out_ref) < tol(dtype, 1e-4, 2e-2)
     assert rel_err(rmd, rm) < 1e-4 and rel_err(rvd, rv) < 1e-4 and int(nbt) == 1
     # ---- backward
     part = torch.empty(ops.bn_bwd_partial_rows(M), 2, C, device=d)
     coef = torch.empty(2, C, device=d)
     dg, db = torch.empty(C, device=d), torch.empty(C, device=d)
     dy = torch.empty((M, C), dtype=dtype, device=d)
-    dres = extra.clone().to(d) if with_res else None
-    ops.bn_act_bwd(dout.to(d), yd, resd, ss, mr, part, coef, dg, db, dy, a, dres, dres)
+    dres = A(extra).clone().to(d) if with_res else None
+    ops.bn_act_bwd(A(dout).to(d), yd, resd, ss, mr, part, coef, dg, db, dy, a, dres, dres)
     be.sync()
-    assert rel_err(dy.float(), yr.grad) < tol(dtype, 2e-4, 3e-2)
+    assert rel_err(Fl(dy), yr.grad) < tol(dtype, 2e-4, 3e-2)
     assert rel_err(dg, gr.grad) < tol(dtype, 2e-4, 2e-2)
     assert rel_err(db, br.grad) < tol(dtype, 2e-4, 2e-2)
     if with_res:
-        assert rel_err(dres.float(), rr.grad + extra.float()) < tol(dtype, 1e-4, 2e-2)
+        assert rel_err(Fl(dres), rr.grad + extra.float()) < tol(dtype, 1e-4, 2e-2)
 
 
 @pytest.mark.parametrize("R,C", [(700, 64), (4608, 128), (129, 72)])
@@ -128,16 +128,16 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
         pytest.skip("the switch only matters for stride 2")
     d = be.device
     w = _rand((Cout, Cin, k, k), torch.float32, 41) / (Cout * k * k) ** 0.5
-    wt = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(d)
+    wt = A(w.permute(1, 2, 3, 0).contiguous().to(dtype)).to(d)
     OH, OW = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
-    dy = _rand((B, OH, OW, Cout), dtype, 42).to(d)
-    res = _rand((B, H, W, Cin), dtype, 43).to(d) if with_res else None
-    y = (_rand((B, H, W, Cin), dtype, 44, 2.0) + 0.5).to(d)                 # raw conv output of the consuming unit
-    bres = _rand((B, H, W, Cin), dtype, 45).to(d) if with_bres else None
+    dy = A(_rand((B, OH, OW, Cout), dtype, 42)).to(d)
+    res = A(_rand((B, H, W, Cin), dtype, 43)).to(d) if with_res else None
+    y = A(_rand((B, H, W, Cin), dtype, 44, 2.0) + 0.5).to(d)                 # raw conv output of the consuming unit
+    bres = A(_rand((B, H, W, Cin), dtype, 45)).to(d) if with_bres else None
     gamma = (1 + 0.2 * _rand((Cin,), torch.float32, 46)).to(d)
     beta = (0.1 * _rand((Cin,), torch.float32, 47)).to(d)
     M = B * H * W
-    yf = y.float().reshape(M, Cin)
+    yf = Fl(y).reshape(M, Cin).to(d)
     mean, var = yf.mean(0), yf.var(0, unbiased=False)
     rstd = (var + 1e-5).rsqrt()
     ss = torch.stack([gamma * rstd, beta - mean * gamma * rstd]).contiguous()
@@ -155,8 +155,8 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
     finally:
         lib.call("mtn_debug_set", 15, 1)
     assert torch.equal(dx, dx_ref)
-    g = dx.float().reshape(M, Cin)
-    pre = yf * ss[0] + ss[1] + (bres.float().reshape(M, Cin) if with_bres else 0)
+    g = Fl(dx).reshape(M, Cin).to(d)
+    pre = yf * ss[0] + ss[1] + (Fl(bres).reshape(M, Cin).to(d) if with_bres else 0)
     sg = torch.sigmoid(pre)
     dz = g * (sg * (1 + pre * (1 - sg))) if act else g
     xh = (yf - mean) * rstd
@@ -172,7 +172,7 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
         dres = torch.empty_like(dyo) if with_bres else None
         ops.bn_act_bwd(dx, y, bres, ss, mr, slab, coef, dg, db, dyo, a, dres=dres, partial_rows=rows)
         be.sync()
-        outs.append((dg.clone(), db.clone(), dyo.float().clone(), None if dres is None else dres.float().clone()))
+        outs.append((dg.clone(), db.clone(), Fl(dyo), None if dres is None else Fl(dres)))
     (dg1, db1, dy1, dr1), (dg0, db0, dy0, dr0) = outs
     scale = float(dg0.abs().max()) + float(db0.abs().max()) + 1e-6
     assert float((dg1 - dg0).abs().max()) < 1e-4 * scale and float((db1 - db0).abs().max()) < 1e-4 * scale

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import GEMM_DTYPES as DTYPES, be, presplit_x3, rel_err, tol, x3_active  # noqa: F401
+from backend import GEMM_DTYPES as DTYPES, A, Fl, be, presplit_x3, rel_err, tol, x3_active  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
@@ -13,7 +13,7 @@ def _rand(shape, dtype, seed):
 
 
 def _wfmt(w, dtype):
-    """kernel weight operand: T-typed, and in the split-bf16 mode (x3 parametrisation) pre-split per 32-k block"""
+    """kernel weight operand: T-typed, and under the x3 parametrisation in split storage like the activations"""
     w = w.contiguous().to(dtype)
     return presplit_x3(w.reshape(w.shape[0], -1)).reshape(w.shape) if (dtype == torch.float32 and x3_active()) else w
 
@@ -62,14 +62,14 @@ def test_conv_fwd_and_stats(be, stages, dtype, cfg):
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), wq, None, s, k // 2).permute(0, 2, 3, 1)
     OH, OW = ref.shape[1:3]
     M = B * OH * OW
-    xd, wd = x.to(be.device), pack_krsc(w, dtype).to(be.device)
+    xd, wd = A(x).to(be.device), pack_krsc(w, dtype).to(be.device)
     y = torch.full((B, OH, OW, Cout), float("nan"), dtype=dtype, device=be.device)
     tiles = ops.conv_stats_tiles(M, Cout, k * k * Cin)
     stats = torch.full((tiles, 2, Cout), float("nan"), dtype=torch.float32, device=be.device)
     ops.conv_fwd(xd, wd, y, stats, k, s)
     be.sync()
-    assert rel_err(y.float(), ref) < tol(dtype)
-    yf = y.float().cpu().reshape(M, Cout)
+    assert rel_err(Fl(y), ref) < tol(dtype)
+    yf = Fl(y).reshape(M, Cout)
     st = stats.cpu().sum(0)
     assert rel_err(st[0], yf.sum(0)) < 1e-4 or float((st[0] - yf.sum(0)).abs().max()) < 1e-3
     assert rel_err(st[1], (yf * yf).sum(0)) < 1e-4
@@ -105,10 +105,10 @@ def test_conv_image_tiles(be, image_tiles, cfg):
     assert tiles == (M + 143) // 144
     y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=d)
     stats = torch.full((tiles, 2, Cout), float("nan"), device=d)
-    ops.conv_fwd(x.to(d), pack_krsc(w, dtype).to(d), y, stats, 3, 1)
+    ops.conv_fwd(A(x).to(d), pack_krsc(w, dtype).to(d), y, stats, 3, 1)
     be.sync()
-    assert rel_err(y.float(), ref) < tol(dtype)
-    yf = y.float().cpu().reshape(M, Cout)
+    assert rel_err(Fl(y), ref) < tol(dtype)
+    yf = Fl(y).reshape(M, Cout)
     assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3 and rel_err(stats.cpu().sum(0)[1], (yf * yf).sum(0)) < 1e-3
     # data gradient of a Cout -> Cin... here the transposed roles: dy has Cout2 = Cin channels in, dx 256-wide out
     if Cout == 256:
@@ -120,9 +120,9 @@ def test_conv_image_tiles(be, image_tiles, cfg):
         yr.backward(dy.float().permute(0, 3, 1, 2))
         dref = xz.grad.permute(0, 2, 3, 1) + res.float()
         dx = res.clone().to(d)
-        ops.conv_dgrad(dy.to(d), pack_crsk(w2, dtype).to(d), dx, dx, 3, 1)
+        ops.conv_dgrad(A(dy).to(d), pack_crsk(w2, dtype).to(d), dx, dx, 3, 1)
         be.sync()
-        assert rel_err(dx.float(), dref) < tol(dtype)
+        assert rel_err(Fl(dx), dref) < tol(dtype)
 
 
 def test_conv_fwd_refuses_a_stats_slab_sized_for_another_tile(be):
@@ -155,10 +155,10 @@ def test_conv_fwd_channel_slices(be, dtype):
     w = _rand((64, 64, 3, 3), torch.float32, 4) / 24.0
     ref = F.conv2d(wide[..., 64:].float().permute(0, 3, 1, 2), w.to(dtype).float(), None, 1, 1).permute(0, 2, 3, 1)
     cat = torch.zeros((B, H, W, 256), dtype=dtype, device=be.device)
-    wided = wide.to(be.device)
+    wided = A(wide).to(be.device)
     ops.conv_fwd(wided[..., 64:], pack_krsc(w, dtype).to(be.device), cat[..., 128:192], None, 3, 1)
     be.sync()
-    assert rel_err(cat[..., 128:192].float(), ref) < tol(dtype)
+    assert rel_err(Fl(cat[..., 128:192]), ref) < tol(dtype)
     assert float(cat[..., :128].float().abs().max()) == 0 and float(cat[..., 192:].float().abs().max()) == 0
 
 
@@ -177,13 +177,13 @@ def test_conv_fwd_forced_128x128_tile(be, dtype, cfg):
     try:
         y = torch.full((B, OH, OW, Cout), float("nan"), dtype=dtype, device=be.device)
         stats = torch.full((ops.conv_stats_tiles(M, Cout, k * k * Cin), 2, Cout), float("nan"), device=be.device)
-        ops.conv_fwd(x.to(be.device), pack_krsc(w, dtype).to(be.device), y, stats, k, s)
+        ops.conv_fwd(A(x).to(be.device), pack_krsc(w, dtype).to(be.device), y, stats, k, s)
         be.sync()
     finally:
         lib.call("mtn_debug_set", 6, 0)
     assert stats.shape[0] == (M + 127) // 128
-    assert rel_err(y.float(), ref) < tol(dtype)
-    yf = y.float().cpu().reshape(M, Cout)
+    assert rel_err(Fl(y), ref) < tol(dtype)
+    yf = Fl(y).reshape(M, Cout)
     assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3
 
 
@@ -207,10 +207,10 @@ def test_conv_dgrad(be, stages, dtype, cfg):
     res = _rand((B, H, W, Cin), dtype, 7)
     yref.backward(dy.float().permute(0, 3, 1, 2))
     ref = x.grad.permute(0, 2, 3, 1) + res.float()
-    dx = res.clone().to(be.device)            # residual aliases the output
-    ops.conv_dgrad(dy.to(be.device), pack_crsk(w, dtype).to(be.device), dx, dx, k, s)
+    dx = A(res).clone().to(be.device)            # residual aliases the output
+    ops.conv_dgrad(A(dy).to(be.device), pack_crsk(w, dtype).to(be.device), dx, dx, k, s)
     be.sync()
-    assert rel_err(dx.float(), ref) < tol(dtype)
+    assert rel_err(Fl(dx), ref) < tol(dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -240,10 +240,10 @@ def test_conv_dgrad_stride2_fused(be, dtype, with_res, cfg):
     wide = torch.full((B, H, W, 2 * Cin), 7.0, dtype=dtype, device=be.device)
     dx = wide[..., :Cin]
     if with_res:
-        dx.copy_(res.to(be.device))
-    ops.conv_dgrad(dy_wide.to(be.device)[..., Cout:], pack_crsk(w, dtype).to(be.device), dx, dx if with_res else None, 3, 2)
+        dx.copy_(A(res).to(be.device))
+    ops.conv_dgrad(A(dy_wide).to(be.device)[..., Cout:], pack_crsk(w, dtype).to(be.device), dx, dx if with_res else None, 3, 2)
     be.sync()
-    assert rel_err(dx.float(), ref) < tol(dtype)
+    assert rel_err(Fl(dx), ref) < tol(dtype)
     assert float((wide[..., Cin:].float() - 7.0).abs().max()) == 0
 
 
@@ -258,11 +258,11 @@ def test_linear_bias_gelu_residual(be, stages, dtype):
     ref = F.gelu(pre) + r.float()
     out = torch.empty((M, N), dtype=dtype, device=be.device)
     aux = torch.empty((M, N), dtype=dtype, device=be.device)
-    ops.linear_fwd(x.to(be.device), _wfmt(w, dtype).to(be.device), out, bias=b.to(be.device),
-                   act=ops.ACT_GELU, aux_out=aux, res=r.to(be.device))
+    ops.linear_fwd(A(x).to(be.device), _wfmt(w, dtype).to(be.device), out, bias=b.to(be.device),
+                   act=ops.ACT_GELU, aux_out=aux, res=A(r).to(be.device))
     be.sync()
-    assert rel_err(aux.float(), pre) < tol(dtype)
-    assert rel_err(out.float(), ref) < tol(dtype)
+    assert rel_err(Fl(aux), pre) < tol(dtype)
+    assert rel_err(Fl(out), ref) < tol(dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -290,7 +290,7 @@ def test_conv_wgrad(be, dtype, tr16, cfg):
         ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, k, s) // 4,
                          dtype=torch.float32, device=be.device)
         dw = torch.full((Cout, Cin, k, k), float("nan"), device=be.device)
-        ops.conv_wgrad(x.to(be.device), dy.to(be.device), dw, ws, k, s)
+        ops.conv_wgrad(A(x).to(be.device), A(dy).to(be.device), dw, ws, k, s)
         be.sync()
     finally:
         lib.call("mtn_debug_set", 1, 1)
@@ -323,7 +323,7 @@ def test_conv_wgrad_kernel_row_tiles(be, dtype, cfg):
         try:
             ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, k, s) // 4, dtype=torch.float32, device=be.device)
             dw = torch.full((Cout, Cin, k, k), float("nan"), device=be.device)
-            ops.conv_wgrad(x.to(be.device), dy.to(be.device), dw, ws, k, s)
+            ops.conv_wgrad(A(x).to(be.device), A(dy).to(be.device), dw, ws, k, s)
             be.sync()
         finally:
             lib.call("mtn_debug_set", 18, 1)
@@ -356,7 +356,7 @@ def test_conv_wgrad_window_kernel(be, dtype, cfg):
         try:
             ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 3, 1) // 4, device=be.device)
             dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=be.device)
-            ops.conv_wgrad(x.to(be.device), dy.to(be.device), dw, ws, 3, 1)
+            ops.conv_wgrad(A(x).to(be.device), A(dy).to(be.device), dw, ws, 3, 1)
             be.sync()
             res.append(dw.cpu())
         finally:
@@ -373,7 +373,7 @@ def test_linear_wgrad_large_m(be, dtype):
     ref = dy.float().t() @ x.float()
     ws = torch.empty(ops.linear_wgrad_workspace_bytes(dtype, M, N, K) // 4, device=be.device)
     dw = torch.empty((N, K), device=be.device)
-    ops.linear_wgrad(x.to(be.device), dy.to(be.device), dw, ws)
+    ops.linear_wgrad(A(x).to(be.device), A(dy).to(be.device), dw, ws)
     be.sync()
     assert rel_err(dw, ref) < tol(dtype, 1e-4, 1e-2)
 
@@ -388,7 +388,7 @@ def test_linear_wgrad_rows_beyond_2_16(be):
     ref = dy.float().t() @ x.float()
     ws = torch.empty(ops.linear_wgrad_workspace_bytes(torch.bfloat16, M, N, K) // 4, device=be.device)
     dw = torch.empty((N, K), device=be.device)
-    ops.linear_wgrad(x.to(be.device), dy.to(be.device), dw, ws)
+    ops.linear_wgrad(A(x).to(be.device), A(dy).to(be.device), dw, ws)
     be.sync()
     assert rel_err(dw, ref) < 1e-2
 
@@ -437,18 +437,6 @@ def test_conv1_fused_stem(be, dtype, cfg):
         lib.call("mtn_debug_set", 11, 0)
 
 
-@pytest.mark.parametrize("cfg", [(2, 16, 16), (3, 32, 32)])
-def test_conv1_backward_on_split_bf16_products(be, cfg):
-    """debug key 21: the fp32 stem backward with its two products (recomputed conv, pixel contraction) as split-bf16
-    MFMAs -- same gates as the exact-f32 form"""
-    from hand_gesture_recognition_amd import lib
-    lib.call("mtn_debug_set", 21, 1)
-    try:
-        _conv1_fused_case(be, torch.float32, *cfg)
-    finally:
-        lib.call("mtn_debug_set", 21, 0)
-
-
 def _conv1_fused_case(be, dtype, B, H, W):
     d = be.device
     x = _rand((B, 3, H, W), torch.float32, 51)
@@ -475,11 +463,11 @@ def _conv1_fused_case(be, dtype, B, H, W):
     rawf = raw.detach().permute(0, 2, 3, 1).reshape(M, 64)
     assert rel_err(stats[:tiles].sum(0)[0], rawf.sum(0)) < 1e-3 or float((stats[:tiles].cpu().sum(0)[0] - rawf.sum(0)).abs().max()) < 1e-3
     assert rel_err(mr[0], rawf.mean(0)) < 1e-4 or float((mr[0].cpu() - rawf.mean(0)).abs().max()) < 1e-5
-    assert rel_err(out.float(), out_ref.permute(0, 2, 3, 1)) < tol(dtype, 1e-4, 2e-2)
+    assert rel_err(Fl(out), out_ref.permute(0, 2, 3, 1)) < tol(dtype, 1e-4, 2e-2)
     rows, width = ops.conv1_bwd_partial_shape(B, H, W)
     part = torch.full((rows, width), float("nan"), device=d)
     dg, db, dw = torch.empty(64, device=d), torch.empty(64, device=d), torch.empty(64, 3, 3, 3, device=d)
-    ops.conv1_bwd(xd, wd, dout.to(d), ss, mr, part, dg, db, dw, ops.ACT_SILU)
+    ops.conv1_bwd(xd, wd, A(dout).to(d), ss, mr, part, dg, db, dw, ops.ACT_SILU)
     be.sync()
     assert rel_err(dg, gr.grad) < tol(dtype, 2e-4, 2e-2) and rel_err(db, br.grad) < tol(dtype, 2e-4, 2e-2)
     assert rel_err(dw, wr.grad) < tol(dtype, 5e-4, 3e-2)
@@ -551,12 +539,12 @@ def test_conv_fwd_pipeline_experiments(be, cfg, stages, tile):
     try:
         y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=be.device)
         stats = torch.full((ops.conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, k, s), 2, Cout), float("nan"), device=be.device)
-        ops.conv_fwd(x.to(be.device), pack_krsc(w, dtype).to(be.device), y, stats, k, s)
+        ops.conv_fwd(A(x).to(be.device), pack_krsc(w, dtype).to(be.device), y, stats, k, s)
         be.sync()
     finally:
         lib.call("mtn_debug_set", 3, 5)
         lib.call("mtn_debug_set", 6, 0)
     assert stats.shape[0] == (M + (255 if tile >= 4 else 127)) // (256 if tile >= 4 else 128)
-    assert rel_err(y.float(), ref) < tol(dtype)
-    yf = y.float().cpu().reshape(M, Cout)
+    assert rel_err(Fl(y), ref) < tol(dtype)
+    yf = Fl(y).reshape(M, Cout)
     assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3

@@ -32,7 +32,7 @@ BUDGETS = [
     ("wgrad3_kernel<bf16_t>", 256, "8 waves, one workgroup per CU"),
     ("wgrad_row3_kernel<bf16_t>", 256, "4 waves x 2 workgroups per CU (80 KB of LDS each)"),
     ("igemm_kernel<bf16_t, 144, 256, 1, 8, 6, 2>", 256, "image tiles: 8 waves, one workgroup per CU"),
-    ("conv1_bwd_kernel<bf16_t, true, true>", 168, "__launch_bounds__(256, 3)"),
+    ("conv1_bwd_kernel<bf16_t, true, true,", 168, "__launch_bounds__(256, 3)"),
 ]
 
 

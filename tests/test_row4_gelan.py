@@ -29,10 +29,10 @@ def _backbone(be, gelan_type, stages, B, S, sd_seed, x_seed, up_seed, dtype=torc
     eng.pack_weights()
     feats = eng.backbone_forward(x.to(be.device), training=True)
     gbuf = eng.stages[-1]["g_out"]
-    gbuf.copy_(up.permute(0, 2, 3, 1).to(be.device).to(gbuf.dtype))
+    eng.set_plain(gbuf, up.permute(0, 2, 3, 1).to(be.device).to(gbuf.dtype))
     eng.backbone_backward(gbuf)
     be.sync()
-    return sd, model, x, up, feats.float().permute(0, 3, 1, 2).cpu()
+    return sd, model, x, up, eng.features_plain(feats).float().permute(0, 3, 1, 2).cpu()
 
 
 def test_oracle_matches_golden_gelan_large(golden_dir):

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import DTYPES, GEMM_DTYPES, be, rel_err, tol  # noqa: F401
+from backend import DTYPES, GEMM_DTYPES, A, Fl, be, rel_err, tol  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
@@ -20,16 +20,16 @@ def test_tokens(be, dtype):
     d = be.device
     feat, pos, cls = _rand((B * P, 256), dtype, 1), _rand((P, 256), torch.float32, 2), _rand((256,), torch.float32, 3)
     tok = torch.empty((B, P + 1, 256), dtype=dtype, device=d)
-    ops.tokens_fwd(feat.to(d), pos.to(d), cls.to(d), tok)
+    ops.tokens_fwd(A(feat).to(d), pos.to(d), cls.to(d), tok)
     ref = torch.cat([cls.expand(B, 1, 256), feat.float().reshape(B, P, 256) + pos], 1)
     be.sync()
-    assert rel_err(tok.float(), ref) < tol(dtype, 1e-6, 1e-2)
+    assert rel_err(Fl(tok), ref) < tol(dtype, 1e-6, 1e-2)
     dtok = _rand((B, P + 1, 256), dtype, 4)
     dfeat = torch.empty((B * P, 256), dtype=dtype, device=d)
     dcls = torch.empty(256, device=d)
-    ops.tokens_bwd(dtok.to(d), dfeat, dcls)
+    ops.tokens_bwd(A(dtok).to(d), dfeat, dcls)
     be.sync()
-    assert rel_err(dfeat.float(), dtok[:, 1:].float().reshape(B * P, 256)) < 1e-6
+    assert rel_err(Fl(dfeat), dtok[:, 1:].float().reshape(B * P, 256)) < tol(dtype, 1e-6, 1e-6)
     assert rel_err(dcls, dtok[:, 0].float().sum(0)) < 1e-5
 
 
@@ -45,16 +45,16 @@ def test_layernorm(be, dtype, M):
     yref.backward(dy.float())
     y = torch.empty((M, 256), dtype=dtype, device=d)
     mr = torch.empty((M, 2), device=d)
-    xd, gd, bd = x.to(d), g.to(d), b.to(d)
+    xd, gd, bd = A(x).to(d), g.to(d), b.to(d)
     ops.layernorm_fwd(xd, gd, bd, y, mr)
     be.sync()
-    assert rel_err(y.float(), yref) < tol(dtype, 1e-5, 1e-2)
+    assert rel_err(Fl(y), yref) < tol(dtype, 1e-5, 1e-2)
     part = torch.empty((ops.rowslab_rows(M), 512), device=d)
     dgb = torch.empty((2, 256), device=d)
-    dx = dres.clone().to(d)
-    ops.layernorm_bwd(dy.to(d), xd, mr, gd, dx, part, dgb, dres=dx)
+    dx = A(dres).clone().to(d)
+    ops.layernorm_bwd(A(dy).to(d), xd, mr, gd, dx, part, dgb, dres=dx)
     be.sync()
-    assert rel_err(dx.float(), xr.grad + dres.float()) < tol(dtype, 1e-4, 2e-2)
+    assert rel_err(Fl(dx), xr.grad + dres.float()) < tol(dtype, 1e-4, 2e-2)
     assert rel_err(dgb[0], gr.grad) < tol(dtype, 1e-4, 1e-2)
     assert rel_err(dgb[1], br.grad) < tol(dtype, 1e-4, 1e-2)
 
@@ -66,12 +66,12 @@ def test_gelu_bwd_and_bias_grad(be, dtype):
     ar = a.float().requires_grad_(True)
     F.gelu(ar).backward(dh.float())
     da = torch.empty_like(a, device=d)
-    ops.gelu_bwd(dh.to(d), a.to(d), da)
+    ops.gelu_bwd(A(dh).to(d), A(a).to(d), da)
     be.sync()
-    assert rel_err(da.float(), ar.grad) < tol(dtype, 1e-5, 1e-2)
+    assert rel_err(Fl(da), ar.grad) < tol(dtype, 1e-5, 1e-2)
     part = torch.empty((ops.rowslab_rows(50), 256), device=d)
     db = torch.empty(256, device=d)
-    ops.bias_grad(dh.to(d), part, db)
+    ops.bias_grad(A(dh).to(d), part, db)
     be.sync()
     assert rel_err(db, dh.float().sum(0)) < 1e-5
 
@@ -94,10 +94,10 @@ def test_linear_gelu_bwd(be, dtype, cfg):
     tiles = ops.linear_gelu_bwd_tiles(M, N, K)
     part = torch.full((ops.slab_rows(tiles), 2, N), float("nan"), device=d)
     wide = torch.full((3 * N,), 7.0, device=d)          # the bias gradient is a slice of the flat gradient buffer
-    ops.linear_gelu_bwd(dh.to(d), wt.to(d), a.to(d), da, part, tiles, wide[N:2 * N])
+    ops.linear_gelu_bwd(A(dh).to(d), A(wt).to(d), A(a).to(d), da, part, tiles, wide[N:2 * N])
     be.sync()
-    assert rel_err(da.float(), ref) < tol(dtype, 1e-5, 1e-2)
-    assert rel_err(wide[N:2 * N], da.float().sum(0)) < 1e-5 or float((wide[N:2 * N] - da.float().sum(0)).abs().max()) < 1e-3
+    assert rel_err(Fl(da), ref) < tol(dtype, 1e-5, 1e-2)
+    assert rel_err(wide[N:2 * N], Fl(da).sum(0)) < 1e-5 or float((wide[N:2 * N] - Fl(da).sum(0)).abs().max()) < 1e-3
     assert float((wide[:N] - 7).abs().max()) == 0 and float((wide[2 * N:] - 7).abs().max()) == 0
 
 
@@ -114,26 +114,26 @@ def test_attention_fwd_bwd(be, dtype, cfg, request):
     D = 32
     if be.name == "emu" and N > 150:
         pytest.skip("long sequences on the GPU only")
-    x3 = request.node.get_closest_marker("x3") is not None        # split-bf16 products: ~1e-5 (N = 577: exact-f32 fallback)
+    x3 = request.node.get_closest_marker("x3") is not None        # split-bf16 products: ~1e-5
     d = be.device
     qkv = _rand((B * N, 3 * H * D), dtype, 12)
     dout = _rand((B * N, H * D), dtype, 13)
     qr = qkv.float().requires_grad_(True)
     oref, aref = _attn_ref(qr, B, N, H, D)
     oref.backward(dout.float())
-    qd = qkv.to(d)
+    qd = A(qkv).to(d)
     out = torch.full((B * N, H * D), float("nan"), dtype=dtype, device=d)
     lse = torch.empty((B * H, N), device=d)
     attn = torch.full((B, H, N, N), float("nan"), device=d)
     ops.attention_fwd(qd, out, lse, attn, B, N, H, D, D ** -0.5)
     be.sync()
-    assert rel_err(out.float(), oref) < tol(dtype, 5e-5 if x3 else 1e-5, 2e-2)
+    assert rel_err(Fl(out), oref) < tol(dtype, 5e-5 if x3 else 1e-5, 2e-2)
     assert rel_err(attn, aref) < tol(dtype, 5e-5 if x3 else 1e-5, 2e-2)
     delta = torch.empty((B * H, N), device=d)
     dqkv = torch.full((B * N, 3 * H * D), float("nan"), dtype=dtype, device=d)
-    ops.attention_bwd(qd, out, dout.to(d), lse, delta, dqkv, B, N, H, D, D ** -0.5)
+    ops.attention_bwd(qd, out, A(dout).to(d), lse, delta, dqkv, B, N, H, D, D ** -0.5)
     be.sync()
-    assert rel_err(dqkv.float(), qr.grad) < tol(dtype, 1e-4 if x3 else 2e-5, 3e-2)
+    assert rel_err(Fl(dqkv), qr.grad) < tol(dtype, 1e-4 if x3 else 2e-5, 3e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -148,7 +148,7 @@ def test_cls_head(be, dtype):
     ps = [t.clone().requires_grad_(True) for t in (lw, lb, W, bias)]
     ref = F.linear(F.layer_norm(tr[:, 0], (256,), ps[0], ps[1], 1e-5), ps[2], ps[3])
     ref.backward(dl)
-    td = tok.to(d)
+    td = A(tok).to(d)
     logits = torch.empty((B, C), device=d)
     xhat, mr = torch.empty((B, 256), device=d), torch.empty((B, 2), device=d)
     lwd, lbd, Wd, bd = lw.to(d), lb.to(d), W.to(d), bias.to(d)
@@ -160,7 +160,7 @@ def test_cls_head(be, dtype):
     part = torch.empty((ops.slab_rows(B), 512), device=d)
     ops.cls_head_bwd(dl.to(d), Wd, lwd, lbd, xhat, mr, dtok, dW, db, dlnwb, part)
     be.sync()
-    assert rel_err(dtok.float(), tr.grad) < tol(dtype, 1e-4, 1e-2)
+    assert rel_err(Fl(dtok), tr.grad) < tol(dtype, 1e-4, 1e-2)
     assert rel_err(dW, ps[2].grad) < 1e-4 and rel_err(db, ps[3].grad) < 1e-4
     assert rel_err(dlnwb[0], ps[0].grad) < 1e-4 and rel_err(dlnwb[1], ps[1].grad) < 1e-4
 
