@@ -65,7 +65,7 @@ def parse():
 _DT = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
 
 
-def igemm_roofline(step, batch):
+def igemm_roofline(step, batch, mode="bf16"):
     """Time every launch of the dominant kernel (the `igemm_kernel` template: every convolution
     forward / data gradient and every ViT linear) inside one real training step.
 
@@ -147,23 +147,30 @@ def igemm_roofline(step, batch):
     # averaged over all instances of the template
     traffic, src = None, None
     import re
-    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic_v\d+\.json$", n)]   # (not the configs' files)
+    tag = "" if mode == "bf16" else mode + "_"
+    tname = {"bf16": "bf16_t", "bf16x3": "f32x3_t", "fp32": "float"}[mode]
+    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic_" + tag + r"v\d+\.json$", n)]   # (not the configs' files)
     # newest collection: highest round, then highest version (r02_..._v3 > r02_..._v2 > r01_..._v10)
     cands.sort(key=lambda n: [int(x) for x in re.findall(r"\d+", n)], reverse=True)
     for name in cands:
         pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-        tot = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
-        n = sum(v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<bf16_t"))
+        tot = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<" + tname))
+        n = sum(v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<" + tname))
         if n:
             traffic, src = round(tot / n), "profiles/" + name
         break
-    return {"bound": "mfma", "kernel": "igemm_kernel<bf16_t,...> (all instances: conv fwd + conv dgrad + ViT linears, one launch per call; not counted: "
+    out = {"bound": "mfma", "kernel": "igemm_kernel<" + tname + ",...> (all instances: conv fwd + conv dgrad + ViT linears, one launch per call; not counted: "
                       "the 4 fc2 data gradients fused with GELU' / bias sums, whose call brackets three launches)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
             "flops_per_launch": round(flops / len(rec)), "algorithmic_bytes_per_launch": round(abytes / len(rec)),
             "share_of_step_ms": round(secs * 1e3, 3), "families": families}
+    if mode == "bf16x3":
+        # `achieved` counts ALGORITHMIC flops (2 M N K); the split-bf16 product issues three bf16 MFMAs per one of them
+        out["mfma_issue_frac"] = round(3 * achieved / MFMA_BF16_PEAK_TFLOPS, 4)
+        out["note"] = "achieved / frac are algorithmic flops against the dense bf16 MFMA roof; each product is three bf16 MFMAs (mfma_issue_frac)"
+    return out
 
 
 def _timed(fn, steps, warmup):
@@ -195,8 +202,20 @@ def validation(a, dev, oracle_ref):
         model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=_DT[mode]).to(dev)
         step = TrainStep(model, a.batch, lr=1e-3)
         batch = synthetic_batch(a.batch, (a.size, a.size), 21, 19, dev, 1234)
-        t = _timed(lambda: step(*batch), 8 if mode == "bf16x3" else 5, 2)
-        out[mode] = {"images_per_sec": round(a.batch / t, 1), "ms_per_step": round(t * 1e3, 3)}
+        if mode == "bf16x3":
+            # the mode that meets the north-star tolerance is timed with the headline's protocol: --warmup steps, then
+            # 1 + --windows windows of --steps steps each, and gets its own roofline object
+            ws = [_timed(lambda: step(*batch), a.steps, a.warmup if i == 0 else 0) * 1e3 for i in range(1 + max(0, a.windows))]
+            out[mode] = {"images_per_sec": round(a.batch / ws[0] * 1e3, 1), "ms_per_step": round(ws[0], 3), "steps": a.steps, "warmup": a.warmup,
+                         "timing_windows": {"ms_per_step": [round(x, 3) for x in ws], "min": round(min(ws), 3),
+                                            "median": round(statistics.median(ws), 3),
+                                            "images_per_sec_at_median": round(a.batch / statistics.median(ws) * 1e3, 1)},
+                         "algorithmic_tflops": round(a.batch / ws[0] * 1e3 * TRAIN_GFLOP_PER_IMG / 1e3, 1) if a.size == 192 else None}
+            if not a.no_roofline:
+                out[mode]["roofline"] = igemm_roofline(step, batch, mode)
+        else:
+            t = _timed(lambda: step(*batch), 5, 2)
+            out[mode] = {"images_per_sec": round(a.batch / t, 1), "ms_per_step": round(t * 1e3, 3), "steps": 5, "warmup": 2}
         del step, model, batch
         torch.cuda.empty_cache()
     if oracle_ref is not None:
@@ -219,6 +238,9 @@ def validation(a, dev, oracle_ref):
             del m
         out["errors_vs_oracle_config1_b4"] = errs
         out["meets_1e-3_on_outputs"] = {m: bool(max(e["logits"], e["heatmaps"], e["attnmap"], e["total_loss"]) < 1e-3) for m, e in errs.items()}
+        # (parameter gradients at B=4 are sums over few pixels of cancelling terms: the reference's own fp32 arithmetic is
+        #  8.2e-4 from a float64 run there -- DESIGN.md section 2b; the split-bf16 mode is gated at 2.5e-3 for this size)
+        out["meets_1e-3_on_grads"] = {m: bool(e["worst_param_grad"] < 1e-3) for m, e in errs.items()}
     return out
 
 
@@ -329,6 +351,29 @@ def cpu_baseline(size, want_ref):
         O.train_step(sd, batch, st, 1e-3)
         n += 1
     dt = time.perf_counter() - t0
+    # SURVEY.md section 8(d)'s two CPU workloads, its protocol (3 warm-up + 10 timed iterations, median), same thread count:
+    # config 1 = B=4 forward + loss (train-mode BatchNorm), and a B=32 full train step
+    def med(fn, warm=3, n_t=10):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n_t):
+            t1 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t1)
+        return statistics.median(ts)
+    sd4, b4 = O.synthetic_state_dict(21, 19, seed=0), O.synthetic_batch(4, size, seed=1234, gaussian_targets=False)
+
+    def fwd_loss():
+        with torch.no_grad():
+            c, h, _ = O.multitasknet_forward(b4[0], sd4, training=True)
+            O.total_loss(c, h, b4[1], b4[2], b4[3])
+    t_c1 = med(fwd_loss)
+    sd32, b32, st32 = O.synthetic_state_dict(21, 19, seed=0), O.synthetic_batch(32, size, seed=1234, gaussian_targets=False), {}
+    t_b32 = med(lambda: O.train_step(sd32, b32, st32, 1e-3))
+    survey = {"protocol": "SURVEY.md 8(d): 3 warm-up + 10 timed iterations, median",
+              "config1_b4_fwd_loss": {"images_per_sec": round(4 / t_c1, 2), "ms": round(t_c1 * 1e3, 1)},
+              "b32_train_step": {"images_per_sec": round(32 / t_b32, 2), "ms": round(t_b32 * 1e3, 1)}}
     ref = None
     if want_ref:
         sd1 = O.synthetic_state_dict(21, 19, seed=0)
@@ -337,7 +382,8 @@ def cpu_baseline(size, want_ref):
         ref = (sd1, b1, outs, losses, grads)
     return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"{n} train steps (fwd+loss+bwd+AdamW) at B={B}, {size}x{size}, fp32, oracle/mtn_oracle.py "
-                      f"(torch-CPU ops), {threads} threads of {os.cpu_count()} logical CPUs"}, ref
+                      f"(torch-CPU ops), {threads} threads of {os.cpu_count()} logical CPUs",
+            "survey_8d": survey}, ref
 
 
 def self_launch(a):

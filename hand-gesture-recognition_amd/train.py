@@ -296,34 +296,109 @@ def build_parser():
     p.add_argument("--save_dir", type=str, default="output")
     p.add_argument("--num_workers", type=int, default=8)
     p.add_argument("--steps_per_epoch", type=int, default=10, help="synthetic steps per epoch")
+    p.add_argument("--val_steps", type=int, default=1, help="synthetic validation batches per epoch (0: no validation, no checkpoints)")
+    p.add_argument("--no_checkpoint", dest="checkpoint", action="store_false", help="skip the best / last checkpoint policy")
     p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32", "bf16x3"])
     return p
 
 
-def run(args, data_cfg):
+class EpochMeters:
+    """The per-step metrics of the reference's training / validation steps (train.py:66-73,90-99,110-121) kept on the device:
+    macro F1 from a running confusion matrix and the count-weighted pose accuracy (PCK of the decoded heat-map maxima) --
+    no host synchronisation per step; ``result()`` reads them once per epoch."""
+
+    def __init__(self, num_classes, device):
+        from .metrics import ClassificationMeter
+        self.cls = ClassificationMeter(num_classes, device)
+        self.acc_sum = torch.zeros((), dtype=torch.float32, device=device)
+        self.cnt = torch.zeros((), dtype=torch.float32, device=device)
+        self.loss_sum = torch.zeros(3, dtype=torch.float32, device=device)
+        self.steps = 0
+
+    def reset(self):
+        self.cls.reset()
+        self.acc_sum.zero_(); self.cnt.zero_(); self.loss_sum.zero_()
+        self.steps = 0
+
+    def update(self, logits, heatmaps, label, target, losses):
+        from .metrics import pose_accuracy
+        self.cls.update(logits, label)
+        _, avg_acc, cnt, _ = pose_accuracy(heatmaps, target)
+        self.acc_sum += avg_acc * cnt                       # train.py:93-94: total_acc += avg_acc * cnt
+        self.cnt += cnt
+        self.loss_sum += losses
+        self.steps += 1
+
+    def result(self, prefix):
+        n = max(self.steps, 1)
+        tot, cl, jl = (float(x) / n for x in self.loss_sum)
+        cnt = float(self.cnt)
+        return {f"{prefix}/total_loss": tot, f"{prefix}/class_loss": cl, f"{prefix}/joints_loss": jl,
+                f"{prefix}/cls_f1score": float(self.cls.f1()), f"{prefix}/pose_acc": float(self.acc_sum) / cnt if cnt > 0 else 0.0}
+
+
+def validate(model, eng, batches, meters):
+    """The reference's validation epoch (train.py:110-138; Lightning runs it under model.eval() and no_grad): forward with the
+    running BatchNorm statistics folded into the weights, the loss recipe without gradients, the same metrics."""
+    was_training = model.training
+    model.eval()
+    meters.reset()
+    with torch.no_grad():
+        for img, label, target, tw in batches:
+            eng.forward(img, training=False, want_attn=False)
+            losses = eng.loss(label, target, tw, with_grads=False)
+            meters.update(eng.logits, eng.hm, label, target, losses)
+    model.train(was_training)
+    return meters.result("val")
+
+
+def run(args, data_cfg, device=None):
+    """The reference's fit loop (train.py:186-240) on synthetic batches: per epoch ``steps_per_epoch`` training steps with
+    the step metrics of train.py:66-73 accumulated on the device, MultiStepLR, a validation pass (``val_steps`` batches of
+    another seed, eval mode) and the checkpoint policy of train.py:214-221 -- ``<save_dir>/<backbone>_<suffix>/weight/
+    best.ckpt`` (top-1 on val/total_loss, min) + ``last.ckpt``, weights only, Lightning-compatible."""
     import os
+    from .checkpoint import CheckpointPolicy
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.devices != world:
         raise SystemExit(f"--devices {args.devices} needs one process per GPU: launch with `python -m "
                          f"torch.distributed.run --nproc-per-node {args.devices} ...` (WORLD_SIZE is {world})")
     local = int(os.environ.get("LOCAL_RANK", str(args.device)))
-    torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl")
+    if device is None:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        if world > 1 and not dist.is_initialized():
+            dist.init_process_group("nccl")
     torch.manual_seed(42)                                                                 # train.py:21
     dt = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.compute_dtype]
-    model = MultiTaskNet(data_cfg["num_joints"], data_cfg["num_classes"], args.image_size, compute_dtype=dt).cuda()
+    J, C = data_cfg["num_joints"], data_cfg["num_classes"]
+    model = MultiTaskNet(J, C, args.image_size, compute_dtype=dt).to(device)
     step = TrainStep(model, args.batch_size, lr=args.lr, lr_step=args.lr_step, lr_factor=args.lr_factor)
-    rank = dist.get_rank() if world > 1 else 0
-    batch = synthetic_batch(args.batch_size, args.image_size, data_cfg["num_joints"], data_cfg["num_classes"],
-                            torch.device("cuda", local), 1234 + rank)
+    rank = dist.get_rank() if (world > 1 and dist.is_initialized()) else 0
+    batch = synthetic_batch(args.batch_size, args.image_size, J, C, device, 1234 + rank)
+    val_batches = [synthetic_batch(args.batch_size, args.image_size, J, C, device, 4321 + 17 * i + rank)
+                   for i in range(max(0, getattr(args, "val_steps", 1)))]
+    train_m, val_m = EpochMeters(C, device), EpochMeters(C, device)
+    save_path = os.path.join(args.save_dir, f"{args.backbone}_{args.suffix}")            # train.py:194-196
+    policy = CheckpointPolicy(os.path.join(save_path, "weight")) if getattr(args, "checkpoint", True) else None
+    history, gstep = [], 0
     for epoch in range(args.epochs):
+        train_m.reset()                                                                   # train.py:140-142
         for _ in range(args.steps_per_epoch):
             losses = step(*batch)
+            train_m.update(step.eng.logits, step.eng.hm, batch[1], batch[2], losses)
+            gstep += 1
         lr = step.epoch_end()
+        log = train_m.result("train")
+        if val_batches:
+            log.update(validate(model, step.eng, val_batches, val_m))
+            if policy is not None:
+                log["checkpoints"] = policy.step(model, log, epoch, gstep, is_main=rank == 0)
+        history.append(log)
         if rank == 0:
-            t, c, j = (float(x) for x in losses)
-            print(f"epoch {epoch}: total {t:.6f} class {c:.6f} joints {j:.6f} lr {lr:g}", flush=True)
+            msg = " ".join(f"{k} {v:.6f}" for k, v in log.items() if isinstance(v, float))
+            print(f"epoch {epoch}: {msg} lr {lr:g}", flush=True)
+    run.history = history
     return model
 
 

@@ -158,31 +158,51 @@ def test_small_fp32_gpu(golden_dir, name):
     _run(Backend("hip"), name, golden_dir, torch.float32, 1e-3, 1e-3)
 
 
+# gradient noise floor of a mode at config-1 sizes, relative to the largest gradient element of the tensor: the gates of the
+# one-step gradient comparison (_run: fp32 1e-3, bf16x3 2.5e-3; bf16 by family, profiles/r03_grad_errors_f64_b4.txt)
+GRAD_NOISE = {torch.float32: 1e-3, "bf16x3": 2.5e-3, torch.bfloat16: 0.15}
+
+
 def _train_steps(be, name, golden_dir, dtype, nsteps, tol_w, use_graph=False):
     from hand_gesture_recognition_amd.train import TrainStep
     g, sd, batch, model = _setup(be, name, golden_dir, dtype)
     dev_batch = tuple(t.to(be.device) for t in batch)
     step = TrainStep(model, batch[0].shape[0], lr=float(g["lr"]), use_graph=use_graph)
     sd_o, st = {k: v.clone() for k, v in sd.items()}, {}
+    ref_grads = []
     for i in range(nsteps):
         losses = step(*dev_batch)
-        (_, _, _), ref_losses, _ = O.train_step(sd_o, batch, st, float(g["lr"]))
+        (_, _, _), ref_losses, grads = O.train_step(sd_o, batch, st, float(g["lr"]))
+        ref_grads.append({k: v.detach().clone() for k, v in grads.items()})
         be.sync()
         assert rel_err(losses, torch.stack(ref_losses)) < tol_w, (i, losses, ref_losses)
-    # Adam normalises every element by |g|, so elements whose gradient is ~0 can flip the sign of
-    # their update under ANY change of summation order: compare element-wise with a budget
-    # (>= 99.5 % of the elements within 10 % of one lr step) and the tensors by norm.
+    # Adam normalises every element by |g|: its first update is -lr * sign(g) whatever |g| is, so an element whose gradient
+    # is below the arithmetic's noise may get the opposite sign from ANY other summation order.  That is the ONLY licence
+    # for an element to differ from the oracle, and it is checked as such: an element whose weight is off by more than a
+    # tenth of a step must have had |g_oracle| below the mode's gradient noise floor (in one of the steps); every other
+    # element agrees, and the tensor restricted to those agrees in norm to 1e-4.
     lr = float(g["lr"])
+    noise = GRAD_NOISE[dtype]
     bad = tot = 0
     for k, p in model.named_parameters():
-        d = (p.detach().cpu() - sd_o[k]).abs()
-        bad += int((d > 0.1 * lr * nsteps).sum())
+        ours, ref = p.detach().cpu(), sd_o[k]
+        d = (ours - ref).abs()
+        off = d > 0.1 * lr * nsteps
+        bad += int(off.sum())
         tot += d.numel()
-        # (one flipped element of a 64-element affine vector moves its norm by 2 lr |x| / |x|^2 ~ 2.5e-4: the small
-        #  tensors get room for two such elements, the large ones average them out)
-        assert abs(float(p.double().norm()) / float(sd_o[k].double().norm()) - 1) < (5e-4 if p.numel() <= 1024 else 1e-4), k
-    assert bad / tot < 5e-3, (bad, tot)
-    if nsteps == 1:
+        if bool(off.any()):
+            # smallest |g| / max|g| the element saw over the oracle's steps (later steps start from weights that already
+            # differ by the earlier licensed flips: twice the floor for them)
+            small = torch.zeros_like(off)
+            for t, gr in enumerate(ref_grads):
+                ga = gr[k].abs()
+                small |= ga <= (1 if t == 0 else 2) * noise * float(ga.max())
+            assert bool((small | ~off).all()), (k, int((off & ~small).sum()), "elements off by > 0.1 lr although their gradient was above the noise floor")
+        keep = ~off
+        rest = float(((ours - ref) * keep).double().norm()) / max(float(ref.double().norm()), 1e-30)
+        assert rest < 1e-4, (k, rest)
+    assert bad / tot < (5e-3 if dtype != torch.bfloat16 else 0.2), (bad, tot)
+    if nsteps == 1 and dtype != torch.bfloat16:
         names = [str(n) for n in g["param_names"]]
         wn = torch.tensor([float(dict(model.named_parameters())[k].double().norm()) for k in names])
         assert rel_err(wn, torch.from_numpy(g["step_weight_norms"])) < tol_w
@@ -207,6 +227,13 @@ def test_train_steps_bf16x3_gpu(golden_dir):
     _train_steps(Backend("hip"), "config1_b4_s192", golden_dir, "bf16x3", 1, 1e-3)
     _train_steps(Backend("hip"), "small_b2_s64", golden_dir, "bf16x3", 3, 2e-3)
     _train_steps(Backend("hip"), "small_b2_s64", golden_dir, "bf16x3", 3, 2e-3, use_graph=True)
+
+
+@pytest.mark.gpu
+def test_train_step_bf16_gpu(golden_dir):
+    """the same licence in the throughput mode: its losses are within its own tolerance, and every weight that leaves the
+    oracle's by more than a tenth of a step had a gradient below bf16's noise floor (profiles/r03_grad_errors_f64_b4.txt)"""
+    _train_steps(Backend("hip"), "config1_b4_s192", golden_dir, torch.bfloat16, 1, 3e-2)
 
 
 @pytest.mark.gpu
