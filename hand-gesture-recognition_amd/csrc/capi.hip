@@ -102,6 +102,7 @@ int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
 int mtn_conv_dgrad_bn_tiles(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
     IgemmArgs p{};
     if (conv_dgrad_args(p, "conv_dgrad_bn_tiles", B, H, W, Cin, Cout, ksize, stride)) return -1;
+    p.bn_y = &p;                 // (the launch this sizes has a BatchNorm hand-over: the kernel choice depends on it)
     return mtn_igemm_stats_tiles(p, dtype);
 }
 
@@ -345,11 +346,11 @@ int mtn_cls_head_bwd(const float* dlogits, const float* W, const float* ln_w, co
 }
 int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B, int h, int w, int J,
                       void* stream) {
-    return mtn_pose_fwd_run(tok, W, bias, hm, mtn_storage_dtype(dtype), B, h, w, J, (hipStream_t)stream);
+    return mtn_pose_fwd_run(tok, W, bias, hm, dtype, B, h, w, J, (hipStream_t)stream);     // (F32X3: plain f32 tokens, split-bf16 products)
 }
 int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                       int dtype, int B, int h, int w, int J, void* stream) {
-    return mtn_pose_bwd_run(tok, W, dhm, dtok, dW_dbias, slab, mtn_storage_dtype(dtype), B, h, w, J, (hipStream_t)stream);
+    return mtn_pose_bwd_run(tok, W, dhm, dtok, dW_dbias, slab, dtype, B, h, w, J, (hipStream_t)stream);
 }
 int mtn_loss_partial_len(long long n) { return mtn_loss_blocks((long)n); }
 int mtn_loss_fwd_bwd(const float* logits, const long long* label, const float* hm, const float* target,
@@ -429,6 +430,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 19) { mtn_igemm_set_x3_waves(value); return MTN_OK; }
     if (key == 20) { mtn_wgrad_set_x3_sep(value); return MTN_OK; }
     if (key == 21) { mtn_conv1_set_x3(value); return MTN_OK; }
+    if (key == 22) { mtn_pw_set(value); return MTN_OK; }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

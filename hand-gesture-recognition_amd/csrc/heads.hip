@@ -1025,6 +1025,8 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_fwd: bad sizes (J=%d, max %d)", J, MAXJ);
     const int OH = 4 * h, OW = 4 * w;
     {
+        const bool x3 = dtype == MTN_F32X3;      // plain f32 tokens, head products as split-bf16 MFMAs (f32s_t, mtn_types.h)
+        if (x3) dtype = MTN_F32;
         const size_t lds = dtype == MTN_BF16 ? pose_fwd_row_lds<bf16_t>(w) : pose_fwd_row_lds<float>(w);
         if (g_pose_row && pose_row_width(w) && lds <= 160 * 1024) {   // row-streaming kernel: all 256 channels per workgroup
             int bands = mtn_cdiv(768, B);                 // >= 768 workgroups (three per CU at B = 256: 42 KB of LDS each)
@@ -1032,6 +1034,7 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
             const int rpb = mtn_cdiv(OH, bands);
             const dim3 grid(mtn_cdiv(OH, rpb), B);
             if (dtype == MTN_BF16) pose_fwd_row_dispatch<bf16_t>(w, grid, lds, stream, tok, W, bias, hm, h, J, rpb);
+            else if (x3) pose_fwd_row_dispatch<f32s_t>(w, grid, lds, stream, tok, W, bias, hm, h, J, rpb);
             else pose_fwd_row_dispatch<float>(w, grid, lds, stream, tok, W, bias, hm, h, J, rpb);
             return mtn_check_launch("pose_fwd_row");
         }
@@ -1113,10 +1116,13 @@ int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dt
                      int dtype, int B, int h, int w, int J, hipStream_t stream) {
     MTN_REQUIRE(B > 0 && h > 0 && w > 0 && J > 0 && J <= MAXJ, "pose_bwd: bad sizes (J=%d, max %d)", J, MAXJ);
     int rc;
+    const bool x3 = dtype == MTN_F32X3;          // plain f32 tokens, products as split-bf16 MFMAs (f32s_t, mtn_types.h)
+    if (x3) dtype = MTN_F32;
     const size_t mma_lds = !g_pose_mma ? 0 : (dtype == MTN_BF16 ? pose_bwd_mma_lds<bf16_t>(h, w) : pose_bwd_mma_lds<float>(h, w));
     const size_t row_lds = dtype == MTN_BF16 ? pose_bwd_row_lds<bf16_t>(w) : pose_bwd_row_lds<float>(w);
     if (g_pose_row && pose_row_width(w) && row_lds <= 160 * 1024 && J <= 32) {
         if (dtype == MTN_BF16) pose_bwd_row_dispatch<bf16_t>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
+        else if (x3) pose_bwd_row_dispatch<f32s_t>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
         else pose_bwd_row_dispatch<float>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
         rc = mtn_check_launch("pose_bwd_row");
     } else if (mma_lds) {

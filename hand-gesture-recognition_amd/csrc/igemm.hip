@@ -991,6 +991,7 @@ int mtn_igemm_tiles_m(int M, int N, int K) {
 
 int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_tiles_m(p);
+    if (mtn_pw_ok(p, dtype)) return mtn_pw_rows(p);
     if (igemm_image_tile_ok(p, dtype == MTN_BF16 ? 2 : 4)) return mtn_cdiv(p.M, IMG_BM);
     if (dtype == MTN_BF16 && ((g_igemm_stages == 7 && g_igemm_tile == 4) || (g_igemm_stages == 5 && g_igemm_tile >= 5)) && igemm_config(p.M, p.N, p.K) == 0)
         return mtn_cdiv(p.M, 256);
@@ -1038,6 +1039,7 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
                      (!p.bn_y || p.bn_ldy % 32 == 0) && (!p.bn_res || p.bn_ldr % 32 == 0)),
                 "igemm: split storage (MTN_DTYPE_F32X3) needs 16-byte aligned operands and row pitches that are multiples of 32");
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
+    if (mtn_pw_ok(p, dtype)) return mtn_pw_run(p, dtype, stream);             // short-K pointwise products: pw.hip
     if (dtype == MTN_F32X3) return dispatch_igemm<f32x3_t>(p, stream);
     return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);
 }

@@ -53,6 +53,10 @@ int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_dgrad2_tiles_m(const IgemmArgs& p);
 int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype);   // rows of the statistics slab this launch would write
 void mtn_dgrad2_set(int on);
+bool mtn_pw_ok(const IgemmArgs& p, int dtype);          // pw.hip: persistent weight-stationary kernel for short-K pointwise products
+int mtn_pw_run(const IgemmArgs& p, int dtype, hipStream_t stream);
+int mtn_pw_rows(const IgemmArgs& p);                    // rows of the statistics slab it writes (one per workgroup of an n-tile)
+void mtn_pw_set(int on);
 
 struct WgradArgs {
     const void* dY; int lddy;     // [M][lddy] output-pixel gradients

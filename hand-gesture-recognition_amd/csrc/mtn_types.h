@@ -18,6 +18,10 @@
 
 struct bf16_t { unsigned short v; };
 struct f32x3_t { float v; };
+// plain f32 in memory and in LDS, but MFMA operands are split into bf16 hi + lo IN REGISTERS when a fragment is loaded and
+// multiplied with three bf16 MFMAs (the split-bf16 product without split storage): the small kernels that stage their own
+// operands in LDS (pose head) under MTN_DTYPE_F32X3
+struct f32s_t { float v; };
 
 #ifdef MTN_EMU
 typedef emu::bf16x8 bf16x8_t;
@@ -47,8 +51,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // v_cvt_pk_bf16_f32: RNE, k
 template <class T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
+template <> __device__ __forceinline__ float to_f<f32s_t>(f32s_t x) { return x.v; }
 template <class T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ f32s_t from_f<f32s_t>(float x) { f32s_t r; r.v = x; return r; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
 // (f32x3_t -- split storage -- has no per-element to_f / from_f: its accessors are ld_vec / st_vec / ld4 / st4 / ld1 below)
 // value as it will read back from storage of type T
@@ -81,6 +87,7 @@ template <> __device__ __forceinline__ void unpack<bf16_t>(const chunk16& c, flo
         f[2 * i] = bf2f(lo); f[2 * i + 1] = bf2f(hi);
     }
 }
+template <> __device__ __forceinline__ void unpack<f32s_t>(const chunk16& c, float* f) { unpack<float>(c, f); }
 template <class T> __device__ __forceinline__ chunk16 pack(const float* f);
 template <> __device__ __forceinline__ chunk16 pack<float>(const float* f) {
     chunk16 c;
@@ -97,6 +104,7 @@ template <> __device__ __forceinline__ chunk16 pack<bf16_t>(const float* f) {
         c[i] = (unsigned)f2bf(f[2 * i]).v | ((unsigned)f2bf(f[2 * i + 1]).v << 16);
     return c;
 }
+template <> __device__ __forceinline__ chunk16 pack<f32s_t>(const float* f) { return pack<float>(f); }
 // four consecutive elements from one accumulator quad (dst 8- / 16-byte aligned)
 template <class T> __device__ __forceinline__ void store4(T* dst, const f32x4_t& v);
 template <> __device__ __forceinline__ void store4<float>(float* dst, const f32x4_t& v) {
@@ -117,6 +125,7 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const f3
     *reinterpret_cast<u32x2_t*>(dst) = o;
 #endif
 }
+template <> __device__ __forceinline__ void store4<f32s_t>(f32s_t* dst, const f32x4_t& v) { store4<float>(reinterpret_cast<float*>(dst), v); }
 __device__ __forceinline__ chunk16 zero_chunk() { chunk16 c; c[0] = 0u; c[1] = 0u; c[2] = 0u; c[3] = 0u; return c; }
 
 // ---- MFMA, 16x16 output tile -------------------------------------------------------------
@@ -221,6 +230,17 @@ template <> struct Mma<f32x3_t> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
 #endif
     }
+};
+
+template <> struct Mma<f32s_t> {
+    static constexpr int KI = 32;
+    typedef Frag3 Frag;
+    // lane group g: 8 consecutive f32 k-values at p (p = row + k0 + 8 g), split in registers
+    static __device__ __forceinline__ Frag load(const f32s_t* p) {
+        const chunk16* q = reinterpret_cast<const chunk16*>(p);
+        return Mma<f32x3_t>::split2(q[0], q[1]);
+    }
+    static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) { return Mma<f32x3_t>::mma(a, b, c); }
 };
 
 __device__ __forceinline__ bf16x8_t load_bf16x8(const void* p) {
@@ -381,6 +401,14 @@ template <class T, bool TR> struct ColFrag;
 template <bool TR> struct ColFrag<float, TR> {
     static __device__ __forceinline__ float load(const float* base, int pitch, int lane) {
         return base[(lane >> 4) * pitch + (lane & 15)];
+    }
+};
+template <bool TR> struct ColFrag<f32s_t, TR> {     // rows k0 + 8 g + j, j = 0..7: the k order of Mma<f32s_t>::load
+    static __device__ __forceinline__ Frag3 load(const f32s_t* base, int pitch, int lane) {
+        const float* p = reinterpret_cast<const float*>(base) + 8 * (lane >> 4) * pitch + (lane & 15);
+        float x[8];
+        MTN_UNROLL for (int j = 0; j < 8; ++j) x[j] = p[j * pitch];
+        return Mma<f32x3_t>::split(x);
     }
 };
 template <> struct ColFrag<bf16_t, false> {

@@ -548,3 +548,84 @@ def test_conv_fwd_pipeline_experiments(be, cfg, stages, tile):
     assert rel_err(Fl(y), ref) < tol(dtype)
     yf = Fl(y).reshape(M, Cout)
     assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3
+
+
+@pytest.fixture
+def pw_forced(be):
+    """the persistent pointwise kernel (pw.hip) on launches of a few tiles"""
+    from hand_gesture_recognition_amd import lib
+    lib.call("mtn_debug_set", 22, 2)
+    yield
+    lib.call("mtn_debug_set", 22, 1)
+
+
+@pytest.mark.parametrize("cfg", [
+    # M, K, N     (bf16; M % 64 == 0; the ring is 3 slots deep at K <= 256, 2 at K = 512)
+    (64, 128, 128),            # one tile, one walker
+    (64 * 9, 256, 128),        # nine tiles on eight walkers: one walker takes two
+    (64 * 29, 128, 256),       # two n-tiles; walkers with 3 and 4 tiles (the steady-state step runs)
+    (64 * 21, 512, 128),       # two-slot ring
+    (64 * 50, 256, 256),       # 16 walkers per n-tile, up to 4 tiles each
+])
+def test_pointwise_persistent_kernel(be, pw_forced, cfg):
+    """pw_kernel: 1x1 convolution forward with statistics (one slab row per workgroup), Linear with bias + GELU + pre-activation
+    copy, and the plain data-gradient form, against torch; the statistics slab has exactly mtn_conv_fwd_stats_tiles rows."""
+    from hand_gesture_recognition_amd import lib
+    M, K, N = cfg
+    dtype, d = torch.bfloat16, be.device
+    x = _rand((1, 1, M, K), dtype, 91)
+    w = _rand((N, K, 1, 1), torch.float32, 92) / K ** 0.5
+    wq = w.to(dtype).float()
+    ref = (x.float().reshape(M, K) @ wq.reshape(N, K).t())
+    rows = ops.conv_fwd_stats_tiles(dtype, 1, 1, M, K, N, 1, 1)
+    lib.call("mtn_debug_set", 22, 0)
+    rows_igemm = ops.conv_fwd_stats_tiles(dtype, 1, 1, M, K, N, 1, 1)
+    lib.call("mtn_debug_set", 22, 2)
+    assert rows % 8 == 0 and rows <= 256 and (rows != rows_igemm or M <= 64 * 8)
+    y = torch.full((1, 1, M, N), float("nan"), dtype=dtype, device=d)
+    stats = torch.full((ops.slab_rows(rows), 2, N), float("nan"), device=d)
+    ops.conv_fwd(x.to(d), pack_krsc(w, dtype).to(d), y, stats, 1, 1, stats_tiles=rows)
+    be.sync()
+    yf = y.float().cpu().reshape(M, N)
+    assert rel_err(yf, ref) < tol(dtype)
+    st = stats[:rows].cpu().sum(0)
+    assert rel_err(st[0], yf.sum(0)) < 1e-3 or float((st[0] - yf.sum(0)).abs().max()) < 1e-2
+    assert rel_err(st[1], (yf * yf).sum(0)) < 1e-3
+    # the same result as igemm.hip's tile for tile (same products, same f32 accumulation order over k)
+    lib.call("mtn_debug_set", 22, 0)
+    y2 = torch.empty_like(y)
+    ops.conv_fwd(x.to(d), pack_krsc(w, dtype).to(d), y2, None, 1, 1)
+    be.sync()
+    lib.call("mtn_debug_set", 22, 2)
+    assert torch.equal(y.cpu().view(torch.int16), y2.cpu().view(torch.int16))
+    # Linear: bias + GELU + pre-activation copy, output into a slice of a wider buffer
+    b = _rand((N,), torch.float32, 93)
+    pre = ref + b
+    wide = torch.full((M, 2 * N), 7.0, dtype=dtype, device=d)
+    aux = torch.full((M, N), float("nan"), dtype=dtype, device=d)
+    ops.linear_fwd(x.reshape(M, K).to(d), _wfmt(w.reshape(N, K), dtype).to(d), wide[:, N:], bias=b.to(d), act=ops.ACT_GELU, aux_out=aux)
+    be.sync()
+    assert rel_err(aux.float(), pre) < tol(dtype)
+    assert rel_err(wide[:, N:].float(), F.gelu(pre)) < tol(dtype)
+    assert float((wide[:, :N].float() - 7.0).abs().max()) == 0
+
+
+@pytest.mark.x3
+@pytest.mark.parametrize("cfg", [(64 * 9, 128), (64 * 29, 256)])
+def test_pointwise_persistent_kernel_split_storage(be, pw_forced, cfg):
+    """pw_kernel<f32x3_t> (K = 128: four 32-channel slabs per row): conv forward with statistics against torch"""
+    M, N = cfg
+    K, dtype, d = 128, torch.float32, be.device
+    x = _rand((1, 1, M, K), dtype, 95)
+    w = _rand((N, K, 1, 1), torch.float32, 96) / K ** 0.5
+    ref = x.reshape(M, K) @ w.reshape(N, K).t()
+    rows = ops.conv_fwd_stats_tiles(dtype, 1, 1, M, K, N, 1, 1)
+    y = torch.full((1, 1, M, N), float("nan"), dtype=dtype, device=d)
+    stats = torch.full((ops.slab_rows(rows), 2, N), float("nan"), device=d)
+    ops.conv_fwd(A(x).to(d), pack_krsc(w, dtype).to(d), y, stats, 1, 1, stats_tiles=rows)
+    be.sync()
+    yf = Fl(y).reshape(M, N)
+    assert rel_err(yf, ref) < 5e-5
+    st = stats[:rows].cpu().sum(0)
+    assert rel_err(st[0], yf.sum(0)) < 1e-3 or float((st[0] - yf.sum(0)).abs().max()) < 1e-2
+    assert rel_err(st[1], (yf * yf).sum(0)) < 1e-3

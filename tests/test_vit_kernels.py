@@ -165,7 +165,7 @@ def test_cls_head(be, dtype):
     assert rel_err(dlnwb[0], ps[0].grad) < 1e-4 and rel_err(dlnwb[1], ps[1].grad) < 1e-4
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", GEMM_DTYPES)      # (x3: the pose head takes PLAIN f32 tokens and multiplies split-bf16)
 @pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17),
                                  (2, 6, 6, 21), (1, 3, 6, 17), (1, 24, 24, 21), (3, 5, 12, 21)])   # widths 6 / 12 / 24: the row-streaming kernels
 def test_pose_head(be, dtype, cfg):
