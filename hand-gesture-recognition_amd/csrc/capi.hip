@@ -410,6 +410,17 @@ int mtn_debug_set(int key, int value) {
                       "before the first call); the product path has no mutable configuration");
         return MTN_ERR_UNSUPPORTED;
     }
+    // keys / values that select a measured-and-rejected variant exist in -DMTN_EXPERIMENTS builds only (the CPU executor library,
+    // diagnostic GPU builds): the product library does not contain those kernels and says so
+    const bool ex = mtn_igemm_has_experiments() != 0;
+    const bool needs_ex = (key == 1 && value == 0) || (key == 3 && value != 5) || (key == 4 && value == 256) || (key == 5 && value == 0) ||
+                          (key == 6 && value >= 4) || (key == 7 && value != 0 && value != 64) || (key == 19 && value != 0 && value != 8) ||
+                          (key == 20 && value != 0) || (key == 8 && value == 5);
+    if (needs_ex && !ex) {
+        mtn_set_error("debug_set: key %d = %d selects a measured-and-rejected kernel variant that this build does not contain "
+                      "(built without -DMTN_EXPERIMENTS)", key, value);
+        return MTN_ERR_UNSUPPORTED;
+    }
     if (key == 1) { mtn_wgrad_set_tr16(value); return MTN_OK; }
     if (key == 2) { mtn_pose_set_dbg(value); return MTN_OK; }
     if (key == 3) { mtn_igemm_set_stages(value); return MTN_OK; }
@@ -431,6 +442,15 @@ int mtn_debug_set(int key, int value) {
     if (key == 20) { mtn_wgrad_set_x3_sep(value); return MTN_OK; }
     if (key == 21) { mtn_conv1_set_x3(value); return MTN_OK; }
     if (key == 22) { mtn_pw_set(value); return MTN_OK; }
+    if (key == 23) {
+#ifdef MTN_EXPERIMENTS
+        mtn_win3_set(value);
+        return MTN_OK;
+#else
+        mtn_set_error("debug_set: key 23 selects a measured-and-rejected kernel (win3.hip) that this build does not contain (-DMTN_EXPERIMENTS)");
+        return MTN_ERR_UNSUPPORTED;
+#endif
+    }
     mtn_set_error("debug_set: unknown key %d", key);
     return MTN_ERR_BAD_ARG;
 }

@@ -888,14 +888,17 @@ int launch_igemm_mode(const IgemmArgs& p, hipStream_t stream) {
         if (igemm_window_ok(p, BM, BN, (int)sizeof(T))) return launch_igemm<T, BM, BN, WGM, WGN, 5, 2>(p, stream);
         return launch_igemm_dma2<T, BM, BN, WGM, WGN>(p, stream);
     }
+#ifdef MTN_EXPERIMENTS       // the pipelines the default replaced (register staging with one / two LDS buffers, three DMA buffers)
     if (g_igemm_stages == 4) return launch_igemm<T, BM, BN, WGM, WGN, 4>(p, stream);
     if (g_igemm_stages == 3) return launch_igemm<T, BM, BN, WGM, WGN, 3>(p, stream);
     if (g_igemm_stages == 2) return launch_igemm<T, BM, BN, WGM, WGN, 2>(p, stream);
     return launch_igemm<T, BM, BN, WGM, WGN, 1>(p, stream);
+#else
+    return MTN_ERR_UNSUPPORTED;
+#endif
 }
 
 static int g_igemm_dbg = 0;
-static int g_x3_waves = 8;       // debug key 19: 4 = the 128x128 tile of the split-bf16 mode runs 2x2 waves
 static int g_igemm_tile = 0;     // debug key 6: 0 = heuristic, 1 = 128x128, 2 = 64x128, 3 = 128x64 (N % 128 == 0 only)
 
 // 0: 128x128, 1: 64x128, 2: 256x64, 3: 128x64
@@ -916,7 +919,9 @@ static int igemm_config(int M, int N, int K) {
         const double e128 = x128 / (double)(long)(x128 + 0.999999);
         return e128 < (K >= 2048 ? 0.5 : 0.6) ? 1 : 0;
     }
+#ifdef MTN_EXPERIMENTS
     if (g_tile_n64 == 256 && M >= 256 * 256) return 2;
+#endif
     return 3;
 }
 
@@ -929,42 +934,41 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     // 128x128 runs with 8 waves (4x2, 32x64 per wave) in the default pipelines: an LDS-DMA
     // instruction costs its wave ~100 cycles of issue, so 4 pieces per wave instead of 8 shorten the
     // load phase of every K step (+5..7 % on these layers; the smaller tiles measured -2..4 %)
-    if constexpr (std::is_same<T, f32x3_t>::value) {
-        // split-bf16 products convert every fragment in registers (24 VALU per fragment): 64x64 wave tiles
-        // (2x2 waves) need 8 fragments per 48 MFMAs where the 8-wave layout needs 6 per 24 (debug key 19)
-        if (cfg == 0 && g_igemm_stages == 5 && g_x3_waves == 4) return launch_igemm_dma2<T, 128, 128, 2, 2>(p, stream);
-        // debug key 19 = 2: register-staged double buffer with split-on-store tiles (each element converted once)
-        if (g_igemm_stages == 5 && g_x3_waves == 2) {
-            if (cfg == 0) return launch_igemm_dma2<T, 128, 128, 4, 2, 2>(p, stream);
-            if (cfg == 1) return launch_igemm_dma2<T, 64, 128, 1, 4, 2>(p, stream);
-            if (cfg == 3) return launch_igemm_dma2<T, 128, 64, 4, 1, 2>(p, stream);
-        }
-    }
+#ifdef MTN_EXPERIMENTS       // measured and rejected: kept for their tests, not in the product library
     if constexpr (sizeof(T) == 2) {
-        // experiments (debug key 6 = 5 / 6): 256x128 tile on 16 waves (4x4, 64x32 per wave), one workgroup per CU, with two
+        // (debug key 6 = 5 / 6): 256x128 tile on 16 waves (4x4, 64x32 per wave), one workgroup per CU, with two
         // and with three LDS buffers -- a quarter less L2->LDS traffic per flop than the 128x128 tile
         if (cfg == 0 && g_igemm_stages == 5 && g_igemm_tile == 5) return launch_igemm_dma2<T, 256, 128, 4, 4>(p, stream);
         if (cfg == 0 && g_igemm_stages == 5 && g_igemm_tile == 6) return launch_igemm_dma2<T, 256, 128, 4, 4, 4>(p, stream);
-        // experiment (debug key 3 = 8): weights through registers, 2x4 waves (64x32 per wave)
+        // (debug key 3 = 8): weights through registers, 2x4 waves (64x32 per wave)
         if (cfg == 0 && g_igemm_stages == 8 && !p.pm && (igemm_pointwise(p) || (p.KH == 3 && p.KW == 3))) {
             if (igemm_pointwise(p) && p.act == MTN_ACT_GELU_GRAD_) return launch_igemm<T, 128, 128, 2, 4, 8, 4>(p, stream);
             if (igemm_pointwise(p)) return launch_igemm<T, 128, 128, 2, 4, 8, 1>(p, stream);
             return launch_igemm<T, 128, 128, 2, 4, 8, 2>(p, stream);
         }
-        // experiment (debug key 3 = 7): ping-pong halves; debug key 6 = 4 picks the 256x128 tile for it
+        // (debug key 3 = 7): ping-pong halves; debug key 6 = 4 picks the 256x128 tile for it
         if (cfg == 0 && g_igemm_stages == 7)
             return g_igemm_tile == 4 ? launch_igemm_dma2<T, 256, 128, 4, 2, 7>(p, stream) : launch_igemm_dma2<T, 128, 128, 4, 2, 7>(p, stream);
     }
+#endif
     if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages >= 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
+#ifdef MTN_EXPERIMENTS
     if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
     if (cfg == 0) return launch_igemm_mode<T, 128, 128, 2, 2>(p, stream);
-    if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
     if (cfg == 2) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
+#endif
+    if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
     return launch_igemm_mode<T, 128, 64, 4, 1>(p, stream);
 }
 }  // namespace
 
+#ifdef MTN_EXPERIMENTS
 void mtn_igemm_set_stages(int n) { g_igemm_stages = ((n >= 1 && n <= 5) || n == 7 || n == 8) ? n : 5; }
+int mtn_igemm_has_experiments(void) { return 1; }
+#else
+void mtn_igemm_set_stages(int n) { (void)n; g_igemm_stages = 5; }
+int mtn_igemm_has_experiments(void) { return 0; }
+#endif
 void mtn_igemm_set_window_limit(int kb) { g_window_limit_kb = (kb > 0 && kb <= 150) ? kb : 53; }
 
 void mtn_igemm_set_image_tiles(int v) { g_image_tiles = v & 3; }
@@ -982,7 +986,7 @@ int mtn_igemm_read_stamps(void* dst, size_t bytes) {
 #endif
 }
 void mtn_igemm_set_dbg(int v) { g_igemm_dbg = v; }
-void mtn_igemm_set_x3_waves(int v) { g_x3_waves = (v == 4 || v == 2) ? v : 8; }
+void mtn_igemm_set_x3_waves(int v) { (void)v; }     // (debug key 19 -- wave layouts of the in-register split -- retired with it in round 4)
 
 int mtn_igemm_tiles_m(int M, int N, int K) {
     static const int bm[4] = {128, 64, 256, 128};
@@ -992,6 +996,7 @@ int mtn_igemm_tiles_m(int M, int N, int K) {
 int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_tiles_m(p);
     if (mtn_pw_ok(p, dtype)) return mtn_pw_rows(p);
+    if (mtn_win3_ok(p, dtype)) return mtn_win3_rows(p);
     if (igemm_image_tile_ok(p, dtype == MTN_BF16 ? 2 : 4)) return mtn_cdiv(p.M, IMG_BM);
     if (dtype == MTN_BF16 && ((g_igemm_stages == 7 && g_igemm_tile == 4) || (g_igemm_stages == 5 && g_igemm_tile >= 5)) && igemm_config(p.M, p.N, p.K) == 0)
         return mtn_cdiv(p.M, 256);
@@ -1040,6 +1045,7 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
                 "igemm: split storage (MTN_DTYPE_F32X3) needs 16-byte aligned operands and row pitches that are multiples of 32");
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
     if (mtn_pw_ok(p, dtype)) return mtn_pw_run(p, dtype, stream);             // short-K pointwise products: pw.hip
+    if (mtn_win3_ok(p, dtype)) return mtn_win3_run(p, dtype, stream);         // 64 -> 64 channel 3x3 stride-1 layers: win3.hip
     if (dtype == MTN_F32X3) return dispatch_igemm<f32x3_t>(p, stream);
     return dtype == MTN_BF16 ? dispatch_igemm<bf16_t>(p, stream) : dispatch_igemm<float>(p, stream);
 }

@@ -57,6 +57,10 @@ bool mtn_pw_ok(const IgemmArgs& p, int dtype);          // pw.hip: persistent we
 int mtn_pw_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_pw_rows(const IgemmArgs& p);                    // rows of the statistics slab it writes (one per workgroup of an n-tile)
 void mtn_pw_set(int on);
+bool mtn_win3_ok(const IgemmArgs& p, int dtype);        // win3.hip: persistent weight-stationary kernel for the 64 -> 64 3x3 stride-1 layers
+int mtn_win3_run(const IgemmArgs& p, int dtype, hipStream_t stream);
+int mtn_win3_rows(const IgemmArgs& p);
+void mtn_win3_set(int on);
 
 struct WgradArgs {
     const void* dY; int lddy;     // [M][lddy] output-pixel gradients
@@ -165,6 +169,7 @@ int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, c
 void mtn_pose_set_dbg(int v);
 void mtn_pose_set_row(int on);
 void mtn_igemm_set_stages(int n);
+int mtn_igemm_has_experiments(void);      // 1 in -DMTN_EXPERIMENTS builds (CPU executor, diagnostics): the rejected variants exist
 
 int mtn_hm_argmax_run(const float* hm, float* preds, float* maxvals, int maps, int H, int W, hipStream_t stream);
 int mtn_pose_acc_run(const float* pred, const float* tgt, float* acc, int B, int J, int H, int W, float thr, hipStream_t stream);

@@ -891,16 +891,18 @@ int launch_wgrad_dma(const WgradArgs& p, hipStream_t stream) {
     mtn_set_max_lds(attr, &wgrad_dma_kernel<T, BN, BC, WGM, WGN>, lds);
 #endif
     const int tiles = (p.N / BN) * (p.K / BC);
+#ifdef MTN_EXPERIMENTS       // separate LDS stages (debug key 20): measured slower in every mode, DESIGN.md section 7d
     if constexpr (std::is_same<T, f32x3_t>::value) {
-        if (BN == 128 && BC == 128 && g_x3_wgrad_sep) {          // split-bf16 mode: separate stages (see wgrad_dma2_kernel)
+        if (BN == 128 && BC == 128 && g_x3_wgrad_sep) {
             MTN_LAUNCH((wgrad_dma2_kernel<T, BN, BC, WGM, WGN, true>), dim3(tiles * p.splits), dim3(NT), 0, stream, p);
             return mtn_check_launch("wgrad_dma2_sep");
         }
     }
-    if (BN == 128 && BC == 128 && WGM * WGN == 8 && g_x3_wgrad_sep == 2) {      // (experiment: separate stages in every mode)
+    if (BN == 128 && BC == 128 && WGM * WGN == 8 && g_x3_wgrad_sep == 2) {
         MTN_LAUNCH((wgrad_dma2_kernel<T, BN, BC, WGM, WGN, true>), dim3(tiles * p.splits), dim3(NT), 0, stream, p);
         return mtn_check_launch("wgrad_dma2_sep");
     }
+#endif
     if (BN == 128 && BC == 128 && WGM * WGN == 8) {
 #ifndef MTN_EMU
         static MtnLdsAttr attr2;
@@ -988,11 +990,21 @@ int mtn_wgrad_row3_splits(int M, int N, int Cin, int dtype, int* rows_per_split)
     if (n >= 8 && tiles <= 24) n = (n + 7) / 8 * 8;
     return (int)n;
 }
+#ifdef MTN_EXPERIMENTS
 void mtn_wgrad_set_dma(int on) { g_wgrad_dma = on; }
 void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t; }
+#else
+void mtn_wgrad_set_dma(int on) { (void)on; g_wgrad_dma = 1; }
+void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t == 64 ? 64 : 0; }      // (64 x 64 tiles are product kernels: the 64-channel layers use them)
+#endif
 void mtn_wgrad_set_slots(int n) { g_wgrad_slots = n > 0 ? n : 0; }
+#ifdef MTN_EXPERIMENTS
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
 void mtn_wgrad_set_x3_sep(int on) { g_x3_wgrad_sep = (on == 1 || on == 2) ? on : 0; }
+#else
+void mtn_wgrad_set_tr16(int on) { (void)on; }
+void mtn_wgrad_set_x3_sep(int on) { (void)on; }
+#endif
 
 // tile of dW owned by one workgroup: BN output channels x BC input channels (of one tap)
 static void wgrad_tile(int N, int Cin, int* bn, int* bc) {
@@ -1038,15 +1050,20 @@ static int wgrad_dispatch(const WgradArgs& p, hipStream_t stream) {
         //  4 waves of 64 x 64 -- 8 fragment conversions per 48 MFMAs instead of 6 per 24 -- were 2 % faster)
         constexpr bool x3 = std::is_same<T, f32x3_t>::value;
         (void)x3;
-        if (bn == 128 && bc == 128) return g_wgrad_tile == 4 ? launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream) : launch_wgrad_dma<T, 128, 128, 4, 2>(p, stream);
+#ifdef MTN_EXPERIMENTS
+        if (bn == 128 && bc == 128 && g_wgrad_tile == 4) return launch_wgrad_dma<T, 128, 128, 2, 2>(p, stream);      // (debug key 7 = 4: 2x2 waves)
+#endif
+        if (bn == 128 && bc == 128) return launch_wgrad_dma<T, 128, 128, 4, 2>(p, stream);
         if (bn == 128) return launch_wgrad_dma<T, 128, 64, 4, 1>(p, stream);
         return launch_wgrad_dma<T, 64, 64, 2, 2>(p, stream);
     }
+#ifdef MTN_EXPERIMENTS       // the register-staged pipeline (debug keys 5 = 0 / 1 = 0) the LDS-DMA kernels replaced in round 1
     if constexpr (!x3_) {
         if (bn == 128 && bc == 128) return launch_wgrad<T, 128, 128, 2, 2, TR>(p, stream);
         if (bn == 128) return launch_wgrad<T, 128, 64, 4, 1, TR>(p, stream);
         return launch_wgrad<T, 64, 64, 2, 2, TR>(p, stream);
     }
+#endif
     return MTN_ERR_UNSUPPORTED;
 }
 
@@ -1088,7 +1105,13 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
         p.magic_oh = (unsigned)(0x100000000ull / h1) + 1u;        // row / (H+1)
         rc = dtype == MTN_BF16 ? launch_wgrad3<bf16_t>(p, stream)
                                : (dtype == MTN_F32X3 ? launch_wgrad3<f32x3_t>(p, stream) : launch_wgrad3<float>(p, stream));
-    } else if (dtype == MTN_BF16) rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
+    } else if (dtype == MTN_BF16) {
+#ifdef MTN_EXPERIMENTS
+        rc = g_use_tr16 ? wgrad_dispatch<bf16_t, true>(p, stream) : wgrad_dispatch<bf16_t, false>(p, stream);
+#else
+        rc = wgrad_dispatch<bf16_t, true>(p, stream);
+#endif
+    }
     else if (dtype == MTN_F32X3) rc = wgrad_dispatch<f32x3_t, false>(p, stream);
     else rc = wgrad_dispatch<float, false>(p, stream);
     if (rc) return rc;

@@ -4,6 +4,7 @@ import torch
 import torch.nn.functional as F
 
 from backend import DTYPES, GEMM_DTYPES, A, Fl, be, rel_err, tol  # noqa: F401
+from backend import dbg  # noqa: E402
 from hand_gesture_recognition_amd import ops
 
 
@@ -143,7 +144,7 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
     ss = torch.stack([gamma * rstd, beta - mean * gamma * rstd]).contiguous()
     mr = torch.stack([mean, rstd]).contiguous()
     a = ops.ACT_SILU if act else ops.ACT_NONE
-    lib.call("mtn_debug_set", 15, fused_s2)
+    dbg(15, fused_s2)
     try:
         dx_ref = torch.empty((B, H, W, Cin), dtype=dtype, device=d)
         ops.conv_dgrad(dy, wt, dx_ref, res, k, s)
@@ -153,7 +154,7 @@ def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
         ops.conv_dgrad(dy, wt, dx, res, k, s, bn=(y, bres, ss, mr, a, part, tiles))
         be.sync()
     finally:
-        lib.call("mtn_debug_set", 15, 1)
+        dbg(15, 1)
     assert torch.equal(dx, dx_ref)
     g = Fl(dx).reshape(M, Cin).to(d)
     pre = yf * ss[0] + ss[1] + (Fl(bres).reshape(M, Cin).to(d) if with_bres else 0)
