@@ -472,8 +472,8 @@ def main():
     extra = [window()[0] / a.steps * 1e3 for _ in range(max(0, a.windows))]
 
     roof = None
-    if not a.no_roofline and a.dtype == "bf16":
-        roof = igemm_roofline(step, batch)          # every rank runs it (the step holds a collective)
+    if not a.no_roofline:
+        roof = igemm_roofline(step, batch, a.dtype)     # every rank runs it (the step holds a collective)
     if rank == 0:
         ips = world * a.batch * a.steps / elapsed
         gflop = TRAIN_GFLOP_PER_IMG if a.size == 192 else (TRAIN_GFLOP_PER_IMG_384 if a.size == 384 else None)

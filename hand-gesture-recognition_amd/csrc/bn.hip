@@ -15,6 +15,9 @@
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
+static int g_bn_fwd_descending = 1;     // debug key 24
+void mtn_bn_set_fwd_order(int descending) { g_bn_fwd_descending = descending ? 1 : 0; }
+
 namespace {
 
 constexpr int kLanes = 16;            // row lanes of the 1024-thread reduction blocks (x 64 columns)
@@ -137,7 +140,7 @@ template <int VEC> struct ChanConst {
 template <class T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ ss,
                                                          const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
-                                                         int M, int C, int act) {
+                                                         int M, int C, int act, int descending) {
     constexpr int VEC = Ev<T>::N;
     const int cpr = C / VEC;
     const int gtid = blockIdx.x * 256 + threadIdx.x;
@@ -145,7 +148,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     const int rstep = gridDim.x * 256 / cpr;           // 256 % cpr == 0 (host-checked)
     ChanConst<VEC> k;
     k.load(ss, C, c);
-    for (int m = gtid / cpr; m < M; m += rstep) {
+    // rows in DESCENDING order (debug key 24 = 0: ascending): the pass then finishes on the first rows of `out`, which are the rows
+    // the consumer -- the next convolution, walking its tiles upwards -- reads first, while they are still in the memory-side cache
+    for (int q = gtid / cpr; q < M; q += rstep) {
+        const int m = descending ? M - 1 - q : q;
         float v[VEC];
         ld_vec<T>(y + (long)m * ldy, c, v);
         MTN_UNROLL for (int e = 0; e < VEC; ++e) v[e] = v[e] * k.a[e] + k.b[e];
@@ -336,13 +342,13 @@ int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res,
     const long total = (long)M * (C / vec);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(bn_act_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16_t*)y, ldy, ss,
-                   (const bf16_t*)res, ldr, (bf16_t*)out, ldo, M, C, act);
+                   (const bf16_t*)res, ldr, (bf16_t*)out, ldo, M, C, act, g_bn_fwd_descending);
     else if (dtype == MTN_F32X3)
         MTN_LAUNCH(bn_act_fwd_kernel<f32x3_t>, dim3(ew_grid(total)), dim3(256), 0, stream, (const f32x3_t*)y, ldy, ss,
-                   (const f32x3_t*)res, ldr, (f32x3_t*)out, ldo, M, C, act);
+                   (const f32x3_t*)res, ldr, (f32x3_t*)out, ldo, M, C, act, g_bn_fwd_descending);
     else
         MTN_LAUNCH(bn_act_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)y, ldy, ss,
-                   (const float*)res, ldr, (float*)out, ldo, M, C, act);
+                   (const float*)res, ldr, (float*)out, ldo, M, C, act, g_bn_fwd_descending);
     return mtn_check_launch("bn_act_fwd");
 }
 

@@ -442,6 +442,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 20) { mtn_wgrad_set_x3_sep(value); return MTN_OK; }
     if (key == 21) { mtn_conv1_set_x3(value); return MTN_OK; }
     if (key == 22) { mtn_pw_set(value); return MTN_OK; }
+    if (key == 24) { mtn_bn_set_fwd_order(value); return MTN_OK; }
     if (key == 23) {
 #ifdef MTN_EXPERIMENTS
         mtn_win3_set(value);

@@ -103,6 +103,7 @@ int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float*
 int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res, int ldr, void* out, int ldo, int dtype,
                        int M, int C, int act, hipStream_t stream);
 int mtn_bn_bwd_blocks(int M);
+void mtn_bn_set_fwd_order(int descending);
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream);
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream);
 int mtn_colsum_ld_run(float* slab, int rows, int W, int ld, float* out, hipStream_t stream);

@@ -5,7 +5,7 @@ import collections, json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from prof_db import clean, load
 
-MFMA = ("igemm_kernel", "wgrad", "dgrad2", "attn_", "pose_", "conv1_")
+MFMA = ("igemm_kernel", "pw_kernel", "wgrad", "dgrad2", "attn_", "pose_", "conv1_")
 st, n = load(sys.argv[1])
 pm = json.load(open(sys.argv[2]))
 agg = collections.defaultdict(lambda: [0.0, 0.0])
