@@ -286,6 +286,9 @@ class Engine:
         self.check_current()
         self.o.pack_weights(self.model.flat_params, self.wpack, self.pack_desc_eval if folded else self.pack_desc,
                          self.pack_n, self.pack_max, scale=self.fold if folded else None)
+        # what the packed copy holds: folded or not, and from which state of the master weights (in-place loads bump the
+        # version; the fused optimizer writes through raw pointers, but a training step always re-packs unfolded first)
+        self._packed = (bool(folded), self.model.flat_params._version)
 
     def fold_batchnorm(self):
         """eval(): scale / shift of every BatchNorm from its running statistics, then the packed weights with the
@@ -394,7 +397,10 @@ class Engine:
         assert tuple(x.shape) == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
         if training:
             self.pack_weights()
-        elif refold:
+        elif refold or getattr(self, "_packed", None) != (True, self.model.flat_params._version):
+            # (refold=False is a promise that the folded weights of the previous eval forward are still current; a training
+            #  forward at this batch size or an in-place weight load since then broke it: fold again instead of serving a
+            #  hybrid of stale folded convolutions and live LayerNorm / head parameters)
             self.fold_batchnorm()
         feats = self.backbone_forward(x, training)
         up = self.u_proj
