@@ -12,11 +12,22 @@
 //           (rowblock_sum) + bn_bwd_finalize -> dgamma, dbeta, mean coefficients
 //           bn_bwd_apply  -> dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)), residual gradient
 // All reductions are slab + ordered sum: deterministic, no float atomics.
+#include <atomic>
 #include "mtn_types.h"
 #include "mtn_kernels.h"
 
 static int g_bn_fwd_descending = 1;     // debug key 24
 void mtn_bn_set_fwd_order(int descending) { g_bn_fwd_descending = descending ? 1 : 0; }
+#ifdef MTN_EXPERIMENTS
+static int g_bn_ticket = 0;             // debug key 26 (experiments builds): 1 = rowblock_sum + finalize kernel as ONE launch
+void mtn_bn_set_ticket(int on) { g_bn_ticket = on ? 1 : 0; }
+
+// Tickets of the fused fold + finalize kernels below: one counter per (launch slot, 64-channel group), zero when no such
+// kernel is running (the block that takes the last ticket resets it).  The host hands out slots round-robin, so two launches
+// share a slot only if kTicketSlots launches lie between them -- more than any queue or captured plan of this library holds.
+constexpr int kTicketSlots = 1024, kTicketGroups = 8;
+__device__ unsigned g_fold_tickets[kTicketSlots][kTicketGroups];
+#endif
 
 namespace {
 
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(1024) void rowblock_sum_grouped_kernel(const ColJob
 }
 
 // block = 16 row-lanes x 64 channels; returns (sum over R rows of part[r][which][c]) in double
-__device__ __forceinline__ void sum2_rows(const float* __restrict__ part, int R, int C, int c, bool valid,
+__device__ __forceinline__ void sum2_rows(const float* part, int R, int C, int c, bool valid,
                                           double& s0, double& s1) {
     __shared__ double red[2][kLanes][64];
     const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
@@ -114,6 +125,149 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
 }
+
+#ifdef MTN_EXPERIMENTS
+// ---- fold + finalize in ONE launch (round 4; MEASURED AND NOT ADOPTED: profiles/r04_tail_ab.txt) -----
+// A dependent launch costs ~5 us of the stream's time however little it does (every rowblock_sum / bn_finalize /
+// bn_bwd_finalize of the round-3 step ran 4.9-5.9 us for ~1 us of work).  The fused form below turned out to cost the same:
+// it is a chain of dependent round trips to the coherent level (store acknowledge, ticket, reload).  Kept for its test
+// and for the fence finding recorded at coherent_store.  Block (x, y) folds row block y of the
+// 64-channel group x exactly as rowblock_sum does, publishes its row (device-scope fence) and takes a ticket; the block
+// that takes the LAST ticket of its group then reads all gridDim.y folded rows and finalizes as bn_finalize /
+// bn_bwd_finalize do -- the same sums in the same order as the two-launch path, so the results are bit-identical to it
+// and independent of which block came last.  No block ever waits for another: nothing here can hang.
+// Memory ordering WITHOUT device-scope fences: __threadfence() compiles to buffer_wbl2 + buffer_inv, a write-back and an
+// invalidate of the XCD's WHOLE L2 per block -- measured +0.33 ms per step (the producer's output, which the next
+// elementwise pass re-reads, sat dirty in those caches).  Instead the few folded rows themselves travel as agent-scope
+// relaxed atomics (sc1 stores / loads: coherent across the XCDs' L2s by themselves), a block waits for its stores to be
+// acknowledged (s_waitcnt vmcnt(0): stores count in vmcnt on gfx9) before thread 0 takes the ticket, and the last block's
+// reads are control-dependent on the ticket it received.
+__device__ __forceinline__ void coherent_store(float* p, float v) {
+#ifdef MTN_EMU
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ float coherent_load(const float* p) {
+#ifdef MTN_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+struct FoldTicket {
+    __device__ __forceinline__ static bool last(int slot) {
+        __shared__ int s_last;
+#ifndef MTN_EMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's part of the folded row has reached the coherent level
+#endif
+        __syncthreads();                                   // ... every thread's, before the ticket is taken
+        if (threadIdx.x == 0) {
+#ifdef MTN_EMU
+            const unsigned t = g_fold_tickets[slot][blockIdx.x]++;
+#else
+            const unsigned t = __hip_atomic_fetch_add(&g_fold_tickets[slot][blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            s_last = t == gridDim.y - 1;
+            if (s_last) g_fold_tickets[slot][blockIdx.x] = 0u;          // (the next use is a later launch)
+        }
+        __syncthreads();
+        return s_last != 0;
+    }
+};
+
+// sum2_rows over rows other blocks of THIS launch wrote (coherent loads)
+__device__ __forceinline__ void sum2_rows_coherent(const float* part, int R, int C, int c, bool valid, double& s0, double& s1) {
+    __shared__ double red[2][kLanes][64];
+    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    // all of a lane's rows (R <= kDirectRows = 16 per lane) are requested before the first is used: these loads miss every
+    // cache by design, one round trip instead of R / 16.  Rows past R add an exact 0.0: the sums are those of sum2_rows.
+    double a = 0.0, b = 0.0;
+    float va[16], vb[16];
+    MTN_UNROLL for (int u = 0; u < 16; ++u) {
+        const int r = tl + kLanes * u;
+        const bool ok = valid && r < R;
+        va[u] = ok ? coherent_load(part + ((long)r * 2 + 0) * C + c) : 0.f;
+        vb[u] = ok ? coherent_load(part + ((long)r * 2 + 1) * C + c) : 0.f;
+    }
+    MTN_UNROLL for (int u = 0; u < 16; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+    red[0][tl][cl] = a;
+    red[1][tl][cl] = b;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    MTN_UNROLL for (int q = 0; q < kLanes; ++q) { s0 += red[0][q][cl]; s1 += red[1][q][cl]; }
+}
+
+// block = 16 row lanes x 64 channels; folds both statistics columns (c, C + c) of rows [y rpb, (y+1) rpb) into out[y]
+__device__ __forceinline__ void fold2_block(const float* in, int rows, int C, int rpb, float* out) {
+    __shared__ float red[2][kLanes][64];
+    const int tl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rpb;
+    int r1 = r0 + rpb;
+    if (r1 > rows) r1 = rows;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int r = r0 + tl; r < r1; r += kLanes) { a += in[((long)r * 2 + 0) * C + c]; b += in[((long)r * 2 + 1) * C + c]; }
+    red[0][tl][cl] = a;
+    red[1][tl][cl] = b;
+    __syncthreads();
+    if (tl < 2 && c < C) {
+        float t = 0.f;
+        MTN_UNROLL for (int q = 0; q < kLanes; ++q) t += red[tl][q][cl];
+        coherent_store(out + ((long)blockIdx.y * 2 + tl) * C + c, t);
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_fold_finalize_kernel(const float* in, int rows, int C, int rpb, float* out, int slot,
+                                                               float count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ rmean,
+                                                               float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                               float momentum, float eps, float* __restrict__ scale_shift,
+                                                               float* __restrict__ mean_rstd) {
+    fold2_block(in, rows, C, rpb, out);
+    if (!FoldTicket::last(slot)) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool valid = c < C;
+    double s, ss;
+    sum2_rows_coherent(out, (int)gridDim.y, C, c, valid, s, ss);
+    if ((threadIdx.x >> 6) == 0 && valid) {
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        scale_shift[c] = sc;
+        scale_shift[C + c] = beta[c] - (float)mean * sc;
+        mean_rstd[c] = (float)mean;
+        mean_rstd[C + c] = rstd;
+        if (rmean) {
+            const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_fold_finalize_kernel(const float* in, int rows, int C, int rpb, float* out,
+                                                                   int slot, float count, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ coef) {
+    fold2_block(in, rows, C, rpb, out);
+    if (!FoldTicket::last(slot)) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool valid = c < C;
+    double s0, s1;
+    sum2_rows_coherent(out, (int)gridDim.y, C, c, valid, s0, s1);
+    if ((threadIdx.x >> 6) == 0 && valid) {
+        dbeta[c] = (float)s0;
+        dgamma[c] = (float)s1;
+        coef[c] = (float)(s0 / count);
+        coef[C + c] = (float)(s1 / count);
+    }
+}
+#endif   // MTN_EXPERIMENTS
 
 // eval mode (model.eval()): normalise with the running statistics
 __global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -310,10 +464,30 @@ static int fold_rows(const float*& part, int& rows, int W, hipStream_t stream, i
     return MTN_OK;
 }
 
+#ifdef MTN_EXPERIMENTS
+// the fused path applies when ONE fold level remains (every shape of the model: <= 32768 producer rows) and the channel
+// groups fit the ticket table
+static bool fold_ticket_ok(int rows, int C) {
+    return g_bn_ticket && rows > kDirectRows && mtn_cdiv(rows, kRowsPerBlock) <= kDirectRows && mtn_cdiv(C, 64) <= kTicketGroups;
+}
+static int next_ticket_slot() {
+    static std::atomic<unsigned> next{0};
+    return (int)(next.fetch_add(1u) % (unsigned)kTicketSlots);
+}
+#endif
+
 int mtn_bn_finalize_run(float* stats, int tiles, int C, long count, const float* gamma, const float* beta,
                         float* rmean, float* rvar, long long* nbt, float momentum, float eps, float* scale_shift,
                         float* mean_rstd, hipStream_t stream) {
     MTN_REQUIRE(tiles > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
+#ifdef MTN_EXPERIMENTS
+    if (fold_ticket_ok(tiles, C)) {
+        MTN_LAUNCH(bn_fold_finalize_kernel, dim3(mtn_cdiv(C, 64), mtn_cdiv(tiles, kRowsPerBlock)), dim3(1024), 0, stream, stats, tiles, C,
+                   kRowsPerBlock, stats + (long)tiles * 2 * C, next_ticket_slot(), (float)count, gamma, beta, rmean, rvar, nbt,
+                   momentum, eps, scale_shift, mean_rstd);
+        return mtn_check_launch("bn_fold_finalize");
+    }
+#endif
     const float* part = stats;
     int rows = tiles;
     int rc = fold_rows(part, rows, 2 * C, stream);
@@ -388,13 +562,26 @@ int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream) {
                    rows_per_block, a.partial);
     int rc = mtn_check_launch("bn_bwd_reduce");
     if (rc) return rc;
-    const float* part = a.partial;
-    int rows = blocks;
-    rc = fold_rows(part, rows, 2 * a.C, stream);
-    if (rc) return rc;
-    MTN_LAUNCH(bn_bwd_finalize_kernel, dim3(mtn_cdiv(a.C, 64)), dim3(1024), 0, stream, part, rows, a.C, (float)a.M,
-               a.dgamma, a.dbeta, a.coef);
-    rc = mtn_check_launch("bn_bwd_finalize");
+#ifdef MTN_EXPERIMENTS
+    const bool ticket = fold_ticket_ok(blocks, a.C);
+    if (ticket) {
+        MTN_LAUNCH(bn_bwd_fold_finalize_kernel, dim3(mtn_cdiv(a.C, 64), mtn_cdiv(blocks, kRowsPerBlock)), dim3(1024), 0, stream, a.partial,
+                   blocks, a.C, kRowsPerBlock, a.partial + (long)blocks * 2 * a.C, next_ticket_slot(), (float)a.M, a.dgamma, a.dbeta,
+                   a.coef);
+        rc = mtn_check_launch("bn_bwd_fold_finalize");
+    }
+#else
+    const bool ticket = false;
+#endif
+    if (!ticket) {
+        const float* part = a.partial;
+        int rows = blocks;
+        rc = fold_rows(part, rows, 2 * a.C, stream);
+        if (rc) return rc;
+        MTN_LAUNCH(bn_bwd_finalize_kernel, dim3(mtn_cdiv(a.C, 64)), dim3(1024), 0, stream, part, rows, a.C, (float)a.M,
+                   a.dgamma, a.dbeta, a.coef);
+        rc = mtn_check_launch("bn_bwd_finalize");
+    }
     if (rc) return rc;
     const long total = (long)a.M * cpr;
     if (dtype == MTN_BF16)

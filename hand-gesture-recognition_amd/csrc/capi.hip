@@ -348,6 +348,10 @@ int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float*
                       void* stream) {
     return mtn_pose_fwd_run(tok, W, bias, hm, dtype, B, h, w, J, (hipStream_t)stream);     // (F32X3: plain f32 tokens, split-bf16 products)
 }
+size_t mtn_pose_slab_floats(int B, int h, int w, int J) {
+    if (B <= 0 || h <= 0 || w <= 0 || J <= 0) return 0;
+    return mtn_pose_slab_floats_run(B, h, w, J);
+}
 int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias, float* slab,
                       int dtype, int B, int h, int w, int J, void* stream) {
     return mtn_pose_bwd_run(tok, W, dhm, dtok, dW_dbias, slab, dtype, B, h, w, J, (hipStream_t)stream);
@@ -443,6 +447,18 @@ int mtn_debug_set(int key, int value) {
     if (key == 21) { mtn_conv1_set_x3(value); return MTN_OK; }
     if (key == 22) { mtn_pw_set(value); return MTN_OK; }
     if (key == 24) { mtn_bn_set_fwd_order(value); return MTN_OK; }
+    if (key == 25) { mtn_pose_set_bands(value); return MTN_OK; }
+    if (key == 26 || key == 27) {
+#ifdef MTN_EXPERIMENTS
+        if (key == 26) mtn_bn_set_ticket(value);
+        else mtn_wgrad_set_skip_reduce(value);              // timing ablation (wrong results)
+        return MTN_OK;
+#else
+        if (value == 0) return MTN_OK;
+        mtn_set_error("debug_set: key %d selects a measured-and-rejected variant (profiles/r04_tail_ab.txt) that this build does not contain (-DMTN_EXPERIMENTS)", key);
+        return MTN_ERR_UNSUPPORTED;
+#endif
+    }
     if (key == 23) {
 #ifdef MTN_EXPERIMENTS
         mtn_win3_set(value);

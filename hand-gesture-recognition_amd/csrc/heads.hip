@@ -712,7 +712,14 @@ static bool pose_row_width(int w);
 template <class T, int WT>
 __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                            const float* __restrict__ dhm, T* __restrict__ dtok,
-                                                           float* __restrict__ slab, int h, int J) {
+                                                           float* __restrict__ slab, float* __restrict__ seam, int h, int J,
+                                                           int nb) {
+    // Bands (round 4): an image is cut into nb bands of source rows [a_k, a_k+1), a_k = h k / nb, one workgroup each
+    // (384x384 images at B = 128 left half the chip idle with one workgroup per image).  Band k walks the output rows
+    // whose upper source row i0 lies in its range; its last row's lower tap a_k+1 is the first row of band k+1, so
+    // exactly ONE source row is shared by neighbours: both write their f32 partial of it to seam[b][k][0 / 1] and
+    // pose_seam_kernel adds the two (one writer per dtok element, fixed order: deterministic).  The weight-gradient
+    // slab has one row per (image, band).
     // 512 threads = 256 channels x 2 halves of the output columns: thread (c, half) recomputes / scatters
     // the columns [half OW/2, (half+1) OW/2) of its channel (literal tap indices need a compile-time
     // column, hence the two instantiations of the column loops below); both halves keep partial
@@ -742,7 +749,13 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
     const int hw = h * w, OH = 4 * h, OHW = OH * OW;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ch = tid & 255, half = tid >> 8;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / nb, band = blockIdx.x - b * nb;
+    const int a_lo = (h * band) / nb, a_hi = (h * (band + 1)) / nb;          // this band's upper-tap source rows [a_lo, a_hi)
+    int oy_lo = 0, oy_hi = OH;                                              // ... and its output rows (i0 is monotone in oy)
+    if (band > 0) { while (lerp_coord(oy_lo, h, OH).i0 < a_lo) ++oy_lo; }
+    if (band < nb - 1) { oy_hi = oy_lo; while (lerp_coord(oy_hi, h, OH).i0 < a_hi) ++oy_hi; }
+    float* const seam_lo = band > 0 ? seam + (((long)b * (nb - 1) + band - 1) * 2 + 1) * w * DIM + ch : nullptr;
+    float* const seam_hi = band < nb - 1 ? seam + (((long)b * (nb - 1) + band) * 2 + 0) * w * DIM + ch : nullptr;
     for (int i = tid; i < DIM * 32; i += NT) {
         const int c = i >> 5, j = i & 31;
         sWt[c * PWT + j] = from_f<T>(j < J ? W[j * DIM + c] : 0.f);
@@ -764,10 +777,10 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
     auto fetch_d = [&](int oy) {
         MTN_UNROLL for (int k = 0; k < ND; ++k) {
             const int i = tid + NT * k, j = i / OW, ox = i - j * OW;
-            dn[k] = (j < J && oy < OH) ? dh[(long)j * OHW + oy * OW + ox] : 0.f;
+            dn[k] = (j < J && oy < oy_hi) ? dh[(long)j * OHW + oy * OW + ox] : 0.f;
         }
     };
-    fetch_d(0);
+    fetch_d(oy_lo);
     float t0[WT], t1[WT], g0[WT], g1[WT], ya[WT], tx[WT];
     MTN_UNROLL for (int sx = 0; sx < WT; ++sx) { g0[sx] = 0.f; g1[sx] = 0.f; }
     unsigned long long mask = 0ull;                  // bit o: u > 0 at column HALF*OW/2 + o
@@ -801,11 +814,15 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
         __syncthreads();                             // everyone is past its reads of sR (the staging aliases it)
         if (half == 1) { MTN_UNROLL for (int sx = 0; sx < WT; ++sx) sF[sx * DIM + ch] = g[sx]; }
         __syncthreads();
-        if (half == 0) { MTN_UNROLL for (int sx = 0; sx < WT; ++sx) drow[(long)(sy * w + sx) * DIM] = from_f<T>(g[sx] + sF[sx * DIM + ch]); }
+        if (half == 0) {
+            float* const sm = (sy == a_lo && seam_lo) ? seam_lo : ((sy == a_hi && seam_hi) ? seam_hi : nullptr);   // workgroup-uniform
+            if (sm) { MTN_UNROLL for (int sx = 0; sx < WT; ++sx) sm[sx * DIM] = g[sx] + sF[sx * DIM + ch]; }
+            else { MTN_UNROLL for (int sx = 0; sx < WT; ++sx) drow[(long)(sy * w + sx) * DIM] = from_f<T>(g[sx] + sF[sx * DIM + ch]); }
+        }
         __syncthreads();                             // staging consumed before the next row's R lands in sR
     };
-    int cur_y0 = -1, cur = 0;
-    for (int oy = 0; oy < OH; ++oy) {
+    int cur_y0 = -1, cur = a_lo;
+    for (int oy = oy_lo; oy < oy_hi; ++oy) {
         const Lerp ly = lerp_coord(oy, h, OH);
         const float wy = ly.w1;
         if (ly.i0 != cur_y0) {                       // workgroup-uniform: new y interval -> its two token rows
@@ -862,7 +879,7 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
     }
     flush(g0, cur);                                  // the last one or two source rows
     if (cur + 1 < h) flush(g1, cur + 1);
-    float* row = slab + (long)b * J * (DIM + 1);
+    float* row = slab + (long)blockIdx.x * J * (DIM + 1);
     MTN_UNROLL for (int q = 0; q < 4; ++q)
         MTN_UNROLL for (int r = 0; r < 4; ++r) {     // accumulator: row = joint, column = channel
             const int j = jf * 16 + 4 * (lane >> 4) + r;
@@ -880,6 +897,32 @@ __global__ __launch_bounds__(512) void pose_bwd_row_kernel(const T* __restrict__
     }
 }
 
+// dtok row a_k+1 of image b = the two band partials of it (pose_bwd_row_kernel); thread = 4 channels of one token
+template <class T>
+__global__ __launch_bounds__(256) void pose_seam_kernel(const float* __restrict__ seam, T* __restrict__ dtok, int B, int h, int w,
+                                                        int nb) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;             // over [B][nb-1][w][DIM/4]
+    const long n = (long)B * (nb - 1) * w * (DIM / 4);
+    if (i >= n) return;
+    const int c = (int)(i % (DIM / 4)) * 4;
+    const int sx = (int)((i / (DIM / 4)) % w);
+    const int k = (int)((i / ((long)(DIM / 4) * w)) % (nb - 1));
+    const int b = (int)(i / ((long)(DIM / 4) * w * (nb - 1)));
+    const float* p = seam + (((long)b * (nb - 1) + k) * 2) * w * DIM + (long)sx * DIM + c;
+    const f32x4_t u = *reinterpret_cast<const f32x4_t*>(p), v = *reinterpret_cast<const f32x4_t*>(p + (long)w * DIM);
+    const int sy = (h * (k + 1)) / nb;
+    f32x4_t o;
+    MTN_UNROLL for (int e = 0; e < 4; ++e) o[e] = u[e] + v[e];
+    store4<T>(dtok + ((long)b * (h * w + 1) + 1 + sy * w + sx) * DIM + c, o);
+}
+
+// bands per image of the row-streaming backward: fill the chip when the batch alone does not (>= 3 source rows per band)
+static int pose_bwd_bands(int B, int h) {
+    int nb = 1;
+    while (nb < 4 && B * nb * 2 <= 256 && h / (nb * 2) >= 3) nb *= 2;
+    return nb;
+}
+
 template <class T>
 static size_t pose_bwd_row_lds(int w) {
     const int OW = 4 * w, OWM = (OW + 15) & ~15, OWK = (OW + 31) & ~31, pad = 16 / (int)sizeof(T);
@@ -888,19 +931,24 @@ static size_t pose_bwd_row_lds(int w) {
 }
 template <class T, int WT>
 static void pose_bwd_row_launch(int B, size_t lds, hipStream_t stream, const void* tok, const float* W, const float* dhm, void* dtok,
-                                float* slab, int h, int J) {
+                                float* slab, float* seam, int h, int J, int nb) {
 #ifndef MTN_EMU
     static MtnLdsAttr attr;
     mtn_set_max_lds(attr, &pose_bwd_row_kernel<T, WT>, 160 * 1024);
 #endif
-    MTN_LAUNCH((pose_bwd_row_kernel<T, WT>), dim3(B), dim3(512), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, h, J);
+    MTN_LAUNCH((pose_bwd_row_kernel<T, WT>), dim3(B * nb), dim3(512), lds, stream, (const T*)tok, W, dhm, (T*)dtok, slab, seam, h, J, nb);
 }
-template <class T>
+// S = storage type of the token gradient (f32s_t computes on plain f32 rows)
+template <class T, class S>
 static void pose_bwd_row_dispatch(int w, int B, size_t lds, hipStream_t stream, const void* tok, const float* W, const float* dhm,
-                                  void* dtok, float* slab, int h, int J) {
-    if (w == 6) pose_bwd_row_launch<T, 6>(B, lds, stream, tok, W, dhm, dtok, slab, h, J);
-    else if (w == 12) pose_bwd_row_launch<T, 12>(B, lds, stream, tok, W, dhm, dtok, slab, h, J);
-    else pose_bwd_row_launch<T, 24>(B, lds, stream, tok, W, dhm, dtok, slab, h, J);
+                                  void* dtok, float* slab, float* seam, int h, int J, int nb) {
+    if (w == 6) pose_bwd_row_launch<T, 6>(B, lds, stream, tok, W, dhm, dtok, slab, seam, h, J, nb);
+    else if (w == 12) pose_bwd_row_launch<T, 12>(B, lds, stream, tok, W, dhm, dtok, slab, seam, h, J, nb);
+    else pose_bwd_row_launch<T, 24>(B, lds, stream, tok, W, dhm, dtok, slab, seam, h, J, nb);
+    if (nb > 1) {
+        const long n = (long)B * (nb - 1) * w * (DIM / 4);
+        MTN_LAUNCH((pose_seam_kernel<S>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seam, (S*)dtok, B, h, w, nb);
+    }
 }
 
 template <class T>
@@ -1011,6 +1059,8 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
 static int g_pose_mma = 1;      // debug key 2: 1 selects the VALU kernels
 static int g_pose_row = 1;      // debug key 14: 0 selects the round-1 chunk/tile kernels
 void mtn_pose_set_row(int on) { g_pose_row = on; }
+static int g_pose_bands = 0;    // debug key 25: bands per image of the row-streaming backward (0 = by batch size)
+void mtn_pose_set_bands(int n) { g_pose_bands = n; }
 static int pose_bwd_rb(int h, int w);
 
 template <class T>
@@ -1120,10 +1170,14 @@ int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dt
     if (x3) dtype = MTN_F32;
     const size_t mma_lds = !g_pose_mma ? 0 : (dtype == MTN_BF16 ? pose_bwd_mma_lds<bf16_t>(h, w) : pose_bwd_mma_lds<float>(h, w));
     const size_t row_lds = dtype == MTN_BF16 ? pose_bwd_row_lds<bf16_t>(w) : pose_bwd_row_lds<float>(w);
+    int slab_rows = B;
     if (g_pose_row && pose_row_width(w) && row_lds <= 160 * 1024 && J <= 32) {
-        if (dtype == MTN_BF16) pose_bwd_row_dispatch<bf16_t>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
-        else if (x3) pose_bwd_row_dispatch<f32s_t>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
-        else pose_bwd_row_dispatch<float>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, h, J);
+        const int nb = g_pose_bands > 0 ? (g_pose_bands <= 4 && h / g_pose_bands >= 3 ? g_pose_bands : 1) : pose_bwd_bands(B, h);
+        slab_rows = B * nb;
+        float* seam = slab + (size_t)mtn_reduce_rows_needed(slab_rows) * J * (DIM + 1);       // after the slab and its folding rows
+        if (dtype == MTN_BF16) pose_bwd_row_dispatch<bf16_t, bf16_t>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, seam, h, J, nb);
+        else if (x3) pose_bwd_row_dispatch<f32s_t, float>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, seam, h, J, nb);
+        else pose_bwd_row_dispatch<float, float>(w, B, row_lds, stream, tok, W, dhm, dtok, slab, seam, h, J, nb);
         rc = mtn_check_launch("pose_bwd_row");
     } else if (mma_lds) {
         if (dtype == MTN_BF16) rc = pose_bwd_mma_launch<bf16_t>(tok, W, dhm, dtok, slab, B, h, w, J, mma_lds, stream);
@@ -1137,7 +1191,14 @@ int mtn_pose_bwd_run(const void* tok, const float* W, const float* dhm, void* dt
         else rc = pose_bwd_launch<float, 16, 0>(tok, W, dhm, dtok, slab, B, h, w, J, stream);
     }
     if (rc) return rc;
-    return mtn_colsum_run(slab, B, J * (DIM + 1), dW_dbias, stream);
+    return mtn_colsum_run(slab, slab_rows, J * (DIM + 1), dW_dbias, stream);
+}
+
+// f32 elements of the scratch mtn_pose_bwd_run needs: [rows + folding rows][J*257] of weight-gradient partials (one row per
+// image and band) followed by the seam rows [B][bands-1][2][w][256]; sized for the most bands any batch of this size takes
+size_t mtn_pose_slab_floats_run(int B, int h, int w, int J) {
+    const int nb = 4;
+    return (size_t)mtn_reduce_rows_needed(B * nb) * J * (DIM + 1) + (size_t)B * (nb - 1) * 2 * w * DIM;
 }
 
 int mtn_loss_blocks(long n) {

@@ -104,6 +104,8 @@ int mtn_bn_act_fwd_run(const void* y, int ldy, const float* ss, const void* res,
                        int M, int C, int act, hipStream_t stream);
 int mtn_bn_bwd_blocks(int M);
 void mtn_bn_set_fwd_order(int descending);
+void mtn_bn_set_ticket(int on);
+void mtn_wgrad_set_skip_reduce(int on);
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream);
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream);
 int mtn_colsum_ld_run(float* slab, int rows, int W, int ld, float* out, hipStream_t stream);
@@ -169,6 +171,8 @@ int mtn_bn_eval_run(const float* gamma, const float* beta, const float* rmean, c
                     float* scale_shift, int C, hipStream_t stream);
 void mtn_pose_set_dbg(int v);
 void mtn_pose_set_row(int on);
+void mtn_pose_set_bands(int n);
+size_t mtn_pose_slab_floats_run(int B, int h, int w, int J);
 void mtn_igemm_set_stages(int n);
 int mtn_igemm_has_experiments(void);      // 1 in -DMTN_EXPERIMENTS builds (CPU executor, diagnostics): the rejected variants exist
 

@@ -999,6 +999,10 @@ void mtn_wgrad_set_tile(int t) { g_wgrad_tile = t == 64 ? 64 : 0; }      // (64 
 #endif
 void mtn_wgrad_set_slots(int n) { g_wgrad_slots = n > 0 ? n : 0; }
 #ifdef MTN_EXPERIMENTS
+static int g_wgrad_skip_reduce = 0;
+void mtn_wgrad_set_skip_reduce(int on) { g_wgrad_skip_reduce = on; }
+#endif
+#ifdef MTN_EXPERIMENTS
 void mtn_wgrad_set_tr16(int on) { g_use_tr16 = on; }
 void mtn_wgrad_set_x3_sep(int on) { g_x3_wgrad_sep = (on == 1 || on == 2) ? on : 0; }
 #else
@@ -1115,6 +1119,9 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     else if (dtype == MTN_F32X3) rc = wgrad_dispatch<f32x3_t, false>(p, stream);
     else rc = wgrad_dispatch<float, false>(p, stream);
     if (rc) return rc;
+#ifdef MTN_EXPERIMENTS
+    if (g_wgrad_skip_reduce) return MTN_OK;              // (timing ablation, debug key 27: the step's result is WRONG)
+#endif
     const long total = (long)p.N * p.K;
     const int blocks = (int)((total / 4 + 31) / 32);
     MTN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p.partial, p.dW, p.splits, p.N, p.K,

@@ -260,7 +260,7 @@ class Engine:
         self.hm = self._f32(B, self.J, 4 * self.fh, 4 * self.fw)
         self.cls_xhat, self.cls_mr = self._f32(B, D), self._f32(B, 2)
         self.cls_part = self._f32(self.o.slab_rows(B), 2 * D)
-        self.pose_slab = self._f32(self.o.slab_rows(B), self.J * (D + 1))
+        self.pose_slab = self._f32(self.o.pose_slab_floats(B, self.fh, self.fw, self.J))
         self.dlogits, self.dhm = self._f32(B, self.C), torch.empty_like(self.hm)
         self.loss_part = self._f32(self.o.loss_partial_len(self.hm.numel()))
         self.losses = self._f32(3)

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "libmtn_hip.so")
+# (MTN_HIP_LIB: a diagnostics build of the same sources, e.g. `make hip EXTRA=-DMTN_EXPERIMENTS OUT=...`, for A/B runs of tools)
+HIP_LIB = os.environ.get("MTN_HIP_LIB") or os.path.join(_HERE, "libmtn_hip.so")
 
 _vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
@@ -62,6 +63,7 @@ _PROTOS = {
     "mtn_cls_head_fwd": [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "mtn_cls_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_pose_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_pose_slab_floats": [_i, _i, _i, _i],
     "mtn_pose_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_loss_partial_len": [_ll],
     "mtn_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
@@ -78,12 +80,12 @@ _PROTOS = {
     "mtn_debug_set": [_i, _i],
     "mtn_debug_read": [_i, _vp, _sz],
 }
-_RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz}
+_RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz, "mtn_pose_slab_floats": _sz}
 _STATUS_FREE = {"mtn_abi_version", "mtn_colsum_rows_per_block", "mtn_colsum_direct_rows", "mtn_rowslab_producer_rows", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
                 "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",
-                "mtn_loss_partial_len"}   # return a value, not a status
+                "mtn_loss_partial_len", "mtn_pose_slab_floats"}   # return a value, not a status
 
 EXPECTED_ABI = 5          # include/mtn.h MTN_ABI_VERSION these prototypes were written for
 

@@ -440,8 +440,12 @@ def pose_head_fwd(tok, W, bias, hm, h, w, mode=None):
              dtype_code(tok, mode), B, h, w, J, _stream(tok))
 
 
+def pose_slab_floats(B, h, w, J):
+    return lib.call("mtn_pose_slab_floats", B, h, w, J)
+
+
 def pose_head_bwd(tok, W, dhm, dtok, dW_dbias, slab, h, w, mode=None):
-    """dW_dbias: f32 [J*256 + J] = weight gradient followed by the bias gradient."""
+    """dW_dbias: f32 [J*256 + J] = weight gradient followed by the bias gradient; slab: f32 [pose_slab_floats(B, h, w, J)]."""
     B, J = dhm.shape[:2]
     lib.call("mtn_pose_head_bwd", tok.data_ptr(), W.data_ptr(), dhm.data_ptr(), dtok.data_ptr(),
              dW_dbias.data_ptr(), slab.data_ptr(), dtype_code(tok, mode), B, h, w, J, _stream(tok))

@@ -249,7 +249,10 @@ int mtn_cls_head_bwd(const float* dlogits, const float* W, const float* ln_w, co
 int mtn_pose_head_fwd(const void* tok, const float* W, const float* bias, float* hm, int dtype, int B,
                       int h, int w, int J, void* stream);
 /* writes dtok rows 1.. and dW_dbias = [dW [J][256] | dbias [J]] (one contiguous f32 block);
- * slab f32 [mtn_slab_rows(B)][J*257] */
+ * slab f32 [mtn_pose_slab_floats(B, h, w, J)]: weight-gradient partials per image and band of source rows, their
+ * folding rows, and the f32 partials of the token-gradient rows two bands share (small batches of large images
+ * are cut into up to 4 bands per image so that the launch fills the chip). */
+size_t mtn_pose_slab_floats(int B, int h, int w, int J);
 int mtn_pose_head_bwd(const void* tok, const float* W, const float* dhm, void* dtok, float* dW_dbias,
                       float* slab, int dtype, int B, int h, int w, int J, void* stream);
 
@@ -315,7 +318,9 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  * key 18 = kernel-row tiles of the 64-channel 3x3 weight gradient (0: one tap per tile);
  * key 3 = 7 / 8 and key 6 = 4 / 5 / 6: measured-and-rejected igemm pipelines kept for their tests (ping-pong wave
  *          halves, weights through registers, 256x128 tiles: DESIGN.md section 7d); keys 19 / 20: split-bf16 tile /
- *          LDS-stage variants; key 21 = retired (accepted, no effect).
+ *          LDS-stage variants; key 21 = retired (accepted, no effect); key 22 = persistent pointwise kernel (0 off,
+ *          2: also K = 512); key 24 = channel-chunk order of bn_act_fwd; key 25 = bands per image of the pose-head
+ *          backward (0 = by batch size); keys 26 / 27 = measured-and-rejected tail variants (experiments builds: profiles/r04_tail_ab.txt).
  * Every key is refused (MTN_ERR_UNSUPPORTED, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
  * call into the library: the product path has no mutable configuration.
  * The environment variable MTN_DEBUG_KEYS="k=v,k=v" applies keys when the binding loads the library.

@@ -355,6 +355,7 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
     const int l = emu::lane(); return emu::shfl_from(v, (l / width) * width + (src % width));
 }
 
+inline void __threadfence() {}      // (blocks run one after another on one host thread)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }

@@ -97,6 +97,65 @@ def test_bn_finalize_many_tile_rows(be, R, C):
     assert rel_err(rv, 0.9 + 0.1 * var * count / (count - 1)) < 1e-6
 
 
+@pytest.mark.parametrize("R,C", [(700, 64), (257, 512), (4608, 128), (18432, 64), (1000, 72)])
+def test_bn_fold_finalize_one_launch_is_the_two_launch_result(be, R, C):
+    """Round 4, measured and not adopted (profiles/r04_tail_ab.txt; -DMTN_EXPERIMENTS builds, debug key 26 = 1): rowblock_sum +
+    bn_finalize as ONE launch (the block that takes the last ticket of its channel group finalizes; bn.hip).  Same sums in
+    the same order -> BIT-identical to the two-launch path, on every repetition (the ticket is left at zero)."""
+    if be.name == "emu" and R > 1000:
+        pytest.skip("large case is for the GPU")
+    g = torch.Generator().manual_seed(R + C)
+    d = be.device
+    count = R * 128
+    stats = torch.zeros(ops.slab_rows(R), 2, C)
+    stats[:R] = torch.randn(R, 2, C, generator=g) * 10 + 3.0
+    stats[:R, 1] = stats[:R, 1].abs() * 40 + 200
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(d), torch.randn(C, generator=g).to(d)
+    got = {}
+    for key, reps in ((0, 1), (1, 3)):
+        dbg(26, key)
+        for rep in range(reps):
+            ss, mr = torch.full((2, C), -7.0, device=d), torch.full((2, C), -7.0, device=d)
+            rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+            nbt = torch.zeros(1, dtype=torch.int64, device=d)
+            sd = stats.to(d)
+            sd[R:] = float("nan")                       # the folding scratch is write-before-read
+            ops.bn_finalize(sd, R, count, gamma, beta, rm, rv, nbt, ss, mr)
+            be.sync()
+            got[(key, rep)] = [t.cpu().clone() for t in (ss, mr, rm, rv, nbt)]
+    dbg(26, 0)
+    for k, v in got.items():
+        for a, b in zip(v, got[(0, 0)]):
+            assert torch.equal(a, b), k
+    assert int(got[(1, 0)][4]) == 1 and torch.isfinite(got[(1, 0)][0]).all()
+
+
+@pytest.mark.parametrize("M,C", [(40000, 64), (17000, 256)])
+def test_bn_bwd_fold_finalize_one_launch_is_the_two_launch_result(be, M, C):
+    g = torch.Generator().manual_seed(M)
+    d = be.device
+    dout, y = torch.randn(M, C, generator=g).bfloat16().to(d), torch.randn(M, C, generator=g).bfloat16().to(d)
+    ss = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)]).to(d)
+    mr = torch.stack([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).to(d)
+    rows = min((M + 63) // 64, 2048)                    # bn_bwd_reduce blocks = producer rows of the slab
+    assert rows > 256, rows                             # (a fold level exists)
+    got = {}
+    for key, reps in ((0, 1), (1, 2)):
+        dbg(26, key)
+        for rep in range(reps):
+            part = torch.full((ops.bn_bwd_partial_rows(M), 2, C), float("nan"), device=d)
+            coef, dg, db = torch.empty(2, C, device=d), torch.empty(C, device=d), torch.empty(C, device=d)
+            dy = torch.empty((M, C), dtype=torch.bfloat16, device=d)
+            ops.bn_act_bwd(dout, y, None, ss, mr, part, coef, dg, db, dy, 1)
+            be.sync()
+            got[(key, rep)] = [t.cpu().clone() for t in (coef, dg, db, dy)]
+    dbg(26, 0)
+    for k, v in got.items():
+        for a, b in zip(v, got[(0, 0)]):
+            assert torch.equal(a, b), k
+    assert torch.isfinite(got[(1, 0)][3].float()).all()
+
+
 def test_bias_grad_many_slab_rows(be):
     """the generic column sum over a slab with hundreds / thousands of rows"""
     M = 5000 if be.name == "emu" else 37120

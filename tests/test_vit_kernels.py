@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import DTYPES, GEMM_DTYPES, A, Fl, be, rel_err, tol  # noqa: F401
+from backend import DTYPES, GEMM_DTYPES, A, Fl, be, dbg, rel_err, tol  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
@@ -167,11 +167,16 @@ def test_cls_head(be, dtype):
 
 @pytest.mark.parametrize("dtype", GEMM_DTYPES)      # (x3: the pose head takes PLAIN f32 tokens and multiplies split-bf16)
 @pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17),
-                                 (2, 6, 6, 21), (1, 3, 6, 17), (1, 24, 24, 21), (3, 5, 12, 21)])   # widths 6 / 12 / 24: the row-streaming kernels
-def test_pose_head(be, dtype, cfg):
+                                 (2, 6, 6, 21), (1, 3, 6, 17), (1, 24, 24, 21), (3, 5, 12, 21),   # widths 6 / 12 / 24: the row-streaming kernels
+                                 (1, 8, 6, 21), (2, 12, 6, 17), (1, 7, 6, 21), (3, 13, 12, 21)])   # ... cut into 2 / 4 bands per image
+@pytest.mark.parametrize("bands", [0, 1])            # debug key 25: 0 = bands by batch size, 1 = one workgroup per image
+def test_pose_head(be, dtype, cfg, bands):
     B, h, w, J = cfg
-    if be.name == "emu" and h * w > 50:
+    if be.name == "emu" and h * w > 80:
         pytest.skip("full-size map on the GPU only")
+    if bands == 1 and (w not in (6, 12, 24) or h < 6):
+        pytest.skip("no bands at this size either way")
+    dbg(25, bands)
     d = be.device
     tok = _rand((B, h * w + 1, 256), dtype, 20)
     W, bias = _rand((J, 256), torch.float32, 21) / 16, 0.1 * _rand((J,), torch.float32, 22)
@@ -189,9 +194,10 @@ def test_pose_head(be, dtype, cfg):
     assert rel_err(hm, ref) < tol(dtype, 1e-4, 1e-2)
     dtok = torch.zeros((B, h * w + 1, 256), dtype=dtype, device=d)
     dwb = torch.empty(J * 257, device=d)
-    slab = torch.empty((ops.slab_rows(B), J * 257), device=d)
+    slab = torch.empty(ops.pose_slab_floats(B, h, w, J), device=d)
     ops.pose_head_bwd(td, Wd, dhm.to(d), dtok, dwb, slab, h, w)
     be.sync()
+    dbg(25, 0)
     dW, db = dwb[:J * 256].view(J, 256), dwb[J * 256:]
     got, want = dtok.float()[:, 1:].cpu(), tr.grad[:, 1:]
     if dtype == torch.float32:
