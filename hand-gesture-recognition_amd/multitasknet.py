@@ -7,12 +7,15 @@ keeps them in one flat fp32 buffer (so AdamW and the RCCL gradient all-reduce ar
 one bucket each) and connects the plan to autograd.
 
 Deviations from the reference module, all deliberate:
-  * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174)
-    and, like the other outputs' backing storage, is overwritten by the next forward;
+  * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174); like the other two
+    outputs it is a fresh tensor per call (a 172 MB copy at B = 256 / 145 tokens: ``share_attnmap = True`` hands out the
+    plan's own buffer instead, which the next forward overwrites -- ``TrainStep`` never copies);
   * the input gets no gradient (``x.grad`` stays None: nothing in the reference's training or export paths asks for it);
   * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode),
     fp32 storage / exact-f32 MFMA (validation mode), or "bf16x3": fp32 storage with split-bf16 matrix
-    products (three MFMAs per product) -- both fp32-storage modes are held to 1e-3 of the reference.
+    products (three MFMAs per product).  Both fp32-storage modes keep logits / heat-maps / attention map within 1e-3 of the
+    reference (measured 2e-6 .. 3e-5); parameter gradients: exact-f32 2e-4, bf16x3 9e-4 at config 1 and up to 1.0e-3 at
+    577 tokens (tests/test_model_parity.py, test_full_size_parity.py state each bound).
 """
 import copy
 import os
@@ -51,6 +54,7 @@ class _PlanFunction(torch.autograd.Function):
     def forward(ctx, anchor, x, model, engine):
         logits, hm, attn = engine.forward(x, training=model.training)
         ctx.model, ctx.engine = model, engine
+        attn = attn if model.share_attnmap else attn.clone()
         ctx.mark_non_differentiable(attn)
         return logits.clone(), hm.clone(), attn
 
@@ -86,6 +90,7 @@ class MultiTaskNet(nn.Module):
             compute_dtype = _DTYPES[compute_dtype.lower()]
         resolve_compute_dtype(compute_dtype)               # (validates)
         self.compute_dtype = compute_dtype
+        self.share_attnmap = False          # True: forward() returns the plan's attention-map buffer itself (no copy)
         self._engines = {}
         self._anchor = None
         self._generation = 0
@@ -218,4 +223,4 @@ class MultiTaskNet(nn.Module):
         if torch.is_grad_enabled() and self.training:
             return _PlanFunction.apply(self._anchor, x, self, eng)
         logits, hm, attn = eng.forward(x, training=self.training)
-        return logits.clone(), hm.clone(), attn
+        return logits.clone(), hm.clone(), (attn if self.share_attnmap else attn.clone())

@@ -164,3 +164,24 @@ def test_parameter_gradients_accumulate_like_autograd():
     w0 = first.detach().clone()
     opt.step()
     assert rel_err(first.detach(), w0 - 0.1 * g[:n0].view_as(w0)) < 1e-6
+
+
+def test_outputs_are_fresh_tensors_per_call():
+    """Like the reference module (plain autograd: every forward allocates its outputs), the three outputs of one call survive
+    the next call -- in train and eval mode; ``share_attnmap`` opts out of the attention-map copy."""
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=8)
+    b0, b1 = O.synthetic_batch(2, 32, seed=21), O.synthetic_batch(2, 32, seed=22)
+    m = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    for train in (True, False):
+        m.train(train)
+        first = m(b0[0])
+        keep = [t.detach().clone() for t in first]
+        second = m(b1[0])
+        for a, k, s in zip(first, keep, second):
+            assert torch.equal(a.detach(), k) and not torch.equal(a.detach(), s.detach())
+        assert not first[2].requires_grad
+    m.share_attnmap = True
+    first = m(b0[0])
+    assert first[2].data_ptr() == m.engine(2).attn.data_ptr()
