@@ -397,13 +397,16 @@ def self_launch(a):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (this pool's host driver: dmabuf IPC only -- RCCL needs it between the ranks)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))                      # (before anything initialises the GPU in this process)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (before the first HIP call of a rank: see self_launch)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
