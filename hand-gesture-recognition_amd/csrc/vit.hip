@@ -73,6 +73,10 @@ __global__ __launch_bounds__(1024) void cls_grad_kernel(const T* __restrict__ dt
 }
 
 // ---- LayerNorm -----------------------------------------------------------------------------------
+// A wave owns LN_R CONSECUTIVE rows and requests all of them before it touches the first (round 4): with one row per loop
+// trip a wave paid a full memory round trip per row (loads at the top of the trip, two dependent wave reductions, store)
+// and the forward needed four rounds of resident waves -- 11.6 / 19.3 us for passes whose bytes move in 6 / 13.
+constexpr int LN_R = 4;
 template <class T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y, int ldy,
@@ -80,56 +84,63 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
     const int lane = threadIdx.x & 63;
     float gm[EPL], bt[EPL];
     MTN_UNROLL for (int e = 0; e < EPL; ++e) { gm[e] = gamma[lane * EPL + e]; bt[e] = beta[lane * EPL + e]; }
-    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += (long)gridDim.x * 4) {
-        float v[EPL];
-        ld4<T>(x + r * ldx, lane * EPL, v);
-        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DIM);
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_R;
+    float v[LN_R][EPL];
+    MTN_UNROLL for (int u = 0; u < LN_R; ++u)
+        if (r0 + u < M) ld4<T>(x + (r0 + u) * ldx, lane * EPL, v[u]);
+    MTN_UNROLL for (int u = 0; u < LN_R; ++u) {
+        const long r = r0 + u;
+        if (r >= M) break;                                        // (wave-uniform)
+        const float mean = wave_sum(v[u][0] + v[u][1] + v[u][2] + v[u][3]) * (1.0f / DIM);
         float d = 0.f;
-        MTN_UNROLL for (int e = 0; e < EPL; ++e) { v[e] -= mean; d += v[e] * v[e]; }
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) { v[u][e] -= mean; d += v[u][e] * v[u][e]; }
         const float rstd = rsqrtf(wave_sum(d) * (1.0f / DIM) + eps);
-        MTN_UNROLL for (int e = 0; e < EPL; ++e) v[e] = v[e] * rstd * gm[e] + bt[e];
-        st4<T>(y + r * ldy, lane * EPL, v);
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) v[u][e] = v[u][e] * rstd * gm[e] + bt[e];
+        st4<T>(y + r * ldy, lane * EPL, v[u]);
         if (mean_rstd && lane == 0) { mean_rstd[2 * r] = mean; mean_rstd[2 * r + 1] = rstd; }
     }
 }
 
 // dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma;
-// partial[block][0][c] = sum dy*xhat (dgamma), partial[block][1][c] = sum dy (dbeta)
+// partial[block][0][c] = sum dy*xhat (dgamma), partial[block][1][c] = sum dy (dbeta); block = 4 waves x LN_R rows
 template <class T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                      const T* __restrict__ dres, int lddres, T* __restrict__ dx, int lddx,
-                                                     float* __restrict__ partial, int M, int rows_per_block) {
+                                                     float* __restrict__ partial, int M) {
     __shared__ float red[4][2][DIM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float gm[EPL], sg[EPL], sb[EPL];
     MTN_UNROLL for (int e = 0; e < EPL; ++e) { gm[e] = gamma[lane * EPL + e]; sg[e] = 0.f; sb[e] = 0.f; }
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
-    for (long r = r0 + w; r < r1; r += 4) {
-        float g[EPL], xv[EPL];
-        ld4<T>(dy + r * lddy, lane * EPL, g);
-        ld4<T>(x + r * ldx, lane * EPL, xv);
-        const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
+    const long r0 = ((long)blockIdx.x * 4 + w) * LN_R;
+    float g[LN_R][EPL], xv[LN_R][EPL], rr[LN_R][EPL], mr[LN_R][2];
+    MTN_UNROLL for (int u = 0; u < LN_R; ++u) {
+        const long r = r0 + u;
+        if (r < M) {
+            ld4<T>(dy + r * lddy, lane * EPL, g[u]);
+            ld4<T>(x + r * ldx, lane * EPL, xv[u]);
+            mr[u][0] = mean_rstd[2 * r]; mr[u][1] = mean_rstd[2 * r + 1];
+            if (dres) ld4<T>(dres + r * lddres, lane * EPL, rr[u]);
+        }
+    }
+    MTN_UNROLL for (int u = 0; u < LN_R; ++u) {
+        const long r = r0 + u;
+        if (r >= M) break;                                        // (wave-uniform)
+        const float mean = mr[u][0], rstd = mr[u][1];
         float a = 0.f, b = 0.f;
         MTN_UNROLL for (int e = 0; e < EPL; ++e) {
-            xv[e] = (xv[e] - mean) * rstd;
-            sg[e] += g[e] * xv[e];
-            sb[e] += g[e];
-            g[e] *= gm[e];
-            a += g[e];
-            b += g[e] * xv[e];
+            xv[u][e] = (xv[u][e] - mean) * rstd;
+            sg[e] += g[u][e] * xv[u][e];
+            sb[e] += g[u][e];
+            g[u][e] *= gm[e];
+            a += g[u][e];
+            b += g[u][e] * xv[u][e];
         }
         a = wave_sum(a) * (1.0f / DIM);
         b = wave_sum(b) * (1.0f / DIM);
-        MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] = rstd * (g[e] - a - xv[e] * b);
-        if (dres) {
-            float rr[EPL];
-            ld4<T>(dres + r * lddres, lane * EPL, rr);
-            MTN_UNROLL for (int e = 0; e < EPL; ++e) g[e] += rr[e];
-        }
-        st4<T>(dx + r * lddx, lane * EPL, g);
+        MTN_UNROLL for (int e = 0; e < EPL; ++e) g[u][e] = rstd * (g[u][e] - a - xv[u][e] * b);
+        if (dres) { MTN_UNROLL for (int e = 0; e < EPL; ++e) g[u][e] += rr[u][e]; }
+        st4<T>(dx + r * lddx, lane * EPL, g[u]);
     }
     MTN_UNROLL for (int e = 0; e < EPL; ++e) { red[w][0][lane * EPL + e] = sg[e]; red[w][1][lane * EPL + e] = sb[e]; }
     __syncthreads();
@@ -338,15 +349,15 @@ int mtn_ln_fwd_run(const void* x, int ldx, const float* gamma, const float* beta
                    int dtype, int M, float eps, hipStream_t stream) {
     MTN_REQUIRE(M > 0 && ldx % 4 == 0 && ldy % 4 == 0, "ln_fwd: bad sizes");
     if (dtype == MTN_BF16)
-        MTN_LAUNCH(ln_fwd_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean_rstd, M, eps);
+        MTN_LAUNCH(ln_fwd_kernel<bf16_t>, dim3(mtn_cdiv(M, 4 * LN_R)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean_rstd, M, eps);
     else if (dtype == MTN_F32X3)
-        MTN_LAUNCH(ln_fwd_kernel<f32x3_t>, dim3(row_grid(M)), dim3(256), 0, stream, (const f32x3_t*)x, ldx, gamma, beta, (f32x3_t*)y, ldy, mean_rstd, M, eps);
+        MTN_LAUNCH(ln_fwd_kernel<f32x3_t>, dim3(mtn_cdiv(M, 4 * LN_R)), dim3(256), 0, stream, (const f32x3_t*)x, ldx, gamma, beta, (f32x3_t*)y, ldy, mean_rstd, M, eps);
     else
-        MTN_LAUNCH(ln_fwd_kernel<float>, dim3(row_grid(M)), dim3(256), 0, stream, (const float*)x, ldx, gamma, beta, (float*)y, ldy, mean_rstd, M, eps);
+        MTN_LAUNCH(ln_fwd_kernel<float>, dim3(mtn_cdiv(M, 4 * LN_R)), dim3(256), 0, stream, (const float*)x, ldx, gamma, beta, (float*)y, ldy, mean_rstd, M, eps);
     return mtn_check_launch("ln_fwd");
 }
 
-static const int kLnRows = 16;     // rows per workgroup (4 per wave): 2320 workgroups at B*N = 37120 fill the chip once
+static const int kLnRows = 4 * LN_R;     // rows per workgroup (LN_R consecutive rows per wave): 2320 workgroups at B*N = 37120
 int mtn_rowslab_blocks(int M) { return mtn_cdiv(M, kLnRows); }
 
 int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float* mean_rstd, const float* gamma,
@@ -356,13 +367,13 @@ int mtn_ln_bwd_run(const void* dy, int lddy, const void* x, int ldx, const float
     const int blocks = mtn_rowslab_blocks(M);
     if (dtype == MTN_BF16)
         MTN_LAUNCH(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean_rstd,
-                   gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partial, M, kLnRows);
+                   gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partial, M);
     else if (dtype == MTN_F32X3)
         MTN_LAUNCH(ln_bwd_kernel<f32x3_t>, dim3(blocks), dim3(256), 0, stream, (const f32x3_t*)dy, lddy, (const f32x3_t*)x, ldx, mean_rstd,
-                   gamma, (const f32x3_t*)dres, lddres, (f32x3_t*)dx, lddx, partial, M, kLnRows);
+                   gamma, (const f32x3_t*)dres, lddres, (f32x3_t*)dx, lddx, partial, M);
     else
         MTN_LAUNCH(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, (const float*)x, ldx, mean_rstd,
-                   gamma, (const float*)dres, lddres, (float*)dx, lddx, partial, M, kLnRows);
+                   gamma, (const float*)dres, lddres, (float*)dx, lddx, partial, M);
     int rc = mtn_check_launch("ln_bwd");
     if (rc) return rc;
     if (!dgamma_dbeta) return MTN_OK;                     // the caller folds the slab later (mtn_colsum_grouped)
