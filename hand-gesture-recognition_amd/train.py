@@ -297,6 +297,7 @@ def build_parser():
     p.add_argument("--num_workers", type=int, default=8)
     p.add_argument("--steps_per_epoch", type=int, default=10, help="synthetic steps per epoch")
     p.add_argument("--val_steps", type=int, default=1, help="synthetic validation batches per epoch (0: no validation, no checkpoints)")
+    p.add_argument("--test_steps", type=int, default=1, help="synthetic test batches after the fit (0: no test epoch)")
     p.add_argument("--no_checkpoint", dest="checkpoint", action="store_false", help="skip the best / last checkpoint policy")
     p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32", "bf16x3"])
     return p
@@ -352,11 +353,55 @@ def validate(model, eng, batches, meters):
     return meters.result("val")
 
 
+def test(model, eng, batches, num_classes, out_dir=None, names=None):
+    """The reference's test epoch (train.py:133-138,176-188; ``trainer.test(module, dm, "best")``): eval-mode forward over the
+    test batches, predicted vs true labels into one confusion matrix on the device, macro F1 printed as the reference prints
+    it, the matrix saved under ``out_dir`` (``confusion_matrix.npy``, and the reference's ``confusion_matrix.png`` when
+    matplotlib is importable).  Rows = predicted class, columns = true class: the reference calls
+    ``confusion_matrix(y_pred, y_true)`` with the arguments in that order (train.py:181)."""
+    import os
+    from .metrics import ClassificationMeter
+    meter = ClassificationMeter(num_classes, batches[0][0].device)
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for img, label, _target, _tw in batches:
+            eng.forward(img, training=False, want_attn=False)
+            meter.update(eng.logits, label)
+    model.train(was_training)
+    f1 = float(meter.f1())
+    cm = meter.cm.t().cpu().numpy()                        # the meter counts [true][pred]
+    print("Test F1 Score: {:.4f}".format(f1), flush=True)                                    # train.py:178
+    if out_dir is not None:
+        import numpy as np
+        os.makedirs(out_dir, exist_ok=True)
+        np.save(os.path.join(out_dir, "confusion_matrix.npy"), cm)
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            fig, ax = plt.subplots(figsize=(10, 10))
+            ax.imshow(cm, cmap="Blues")
+            ticks = list(names) if names is not None else list(range(num_classes))
+            ax.set_xticks(range(num_classes), ticks, rotation=90)
+            ax.set_yticks(range(num_classes), ticks)
+            for i in range(num_classes):
+                for j in range(num_classes):
+                    ax.text(j, i, int(cm[i, j]), ha="center", va="center")
+            plt.tight_layout()
+            plt.savefig(os.path.join(out_dir, "confusion_matrix.png"))
+            plt.close(fig)
+        except Exception:                                  # plotting is a convenience of the reference, not a result
+            pass
+    return f1, cm
+
+
 def run(args, data_cfg, device=None):
     """The reference's fit loop (train.py:186-240) on synthetic batches: per epoch ``steps_per_epoch`` training steps with
     the step metrics of train.py:66-73 accumulated on the device, MultiStepLR, a validation pass (``val_steps`` batches of
-    another seed, eval mode) and the checkpoint policy of train.py:214-221 -- ``<save_dir>/<backbone>_<suffix>/weight/
-    best.ckpt`` (top-1 on val/total_loss, min) + ``last.ckpt``, weights only, Lightning-compatible."""
+    another seed, eval mode) and the checkpoint policy of train.py:214-221 -- ``<save_dir>/<backbone>_<H>x<W>_<suffix>/weight/
+    best.ckpt`` (top-1 on val/total_loss, min) + ``last.ckpt``, weights only, Lightning-compatible -- then the test epoch on
+    the best checkpoint (train.py:239-240)."""
     import os
     from .checkpoint import CheckpointPolicy
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -379,7 +424,8 @@ def run(args, data_cfg, device=None):
     val_batches = [synthetic_batch(args.batch_size, args.image_size, J, C, device, 4321 + 17 * i + rank)
                    for i in range(max(0, getattr(args, "val_steps", 1)))]
     train_m, val_m = EpochMeters(C, device), EpochMeters(C, device)
-    save_path = os.path.join(args.save_dir, f"{args.backbone}_{args.suffix}")            # train.py:194-196
+    save_path = os.path.join(args.save_dir, "{}_{}x{}_{}".format(args.backbone, args.image_size[0], args.image_size[1],
+                                                                 args.suffix))           # train.py:190-193
     policy = CheckpointPolicy(os.path.join(save_path, "weight")) if getattr(args, "checkpoint", True) else None
     history, gstep = [], 0
     for epoch in range(args.epochs):
@@ -398,7 +444,18 @@ def run(args, data_cfg, device=None):
         if rank == 0:
             msg = " ".join(f"{k} {v:.6f}" for k, v in log.items() if isinstance(v, float))
             print(f"epoch {epoch}: {msg} lr {lr:g}", flush=True)
-    run.history = history
+    run.history, run.test_result = history, None
+    test_steps = max(0, getattr(args, "test_steps", 1))
+    if test_steps:                                                                        # train.py:239-240
+        if world > 1:
+            dist.barrier()                                                                # (rank 0 has written best.ckpt)
+        best = os.path.join(save_path, "weight", "best.ckpt")
+        if policy is not None and os.path.exists(best):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(best, model)                                                  # trainer.test(..., "best"): every rank
+        batches = [synthetic_batch(args.batch_size, args.image_size, J, C, device, 9876 + 13 * i + rank) for i in range(test_steps)]
+        run.test_result = test(model, step.eng, batches, C, out_dir=save_path if rank == 0 else None,
+                               names=(data_cfg.get("names") or {}).keys() or None)
     return model
 
 

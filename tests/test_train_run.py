@@ -29,7 +29,7 @@ def test_run_loop_metrics_validation_checkpoints_emu(tmp_path, dtype):
             assert k in log and log[k] == log[k], (k, log)
         assert 0.0 <= log["train/pose_acc"] <= 1.0 and 0.0 <= log["val/cls_f1score"] <= 1.0
         assert abs(log["train/total_loss"] - log["train/class_loss"] - log["train/joints_loss"]) < 1e-5
-    wdir = os.path.join(str(tmp_path), "gelans_t", "weight")
+    wdir = os.path.join(str(tmp_path), "gelans_32x32_t", "weight")                       # train.py:190-193
     assert os.path.exists(os.path.join(wdir, "last.ckpt")) and os.path.exists(os.path.join(wdir, "best.ckpt"))
     # best = the epoch with the smallest val/total_loss, last = the final weights; both load with the reference's loader recipe
     best_epoch = min(range(3), key=lambda e: hist[e]["val/total_loss"])
@@ -38,10 +38,18 @@ def test_run_loop_metrics_validation_checkpoints_emu(tmp_path, dtype):
     fresh = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
     last = load_checkpoint(os.path.join(wdir, "last.ckpt"), fresh)
     assert last["epoch"] == 2
+    # ... and, as after the reference's trainer.test(module, dm, "best"), the returned module holds the BEST weights
+    load_checkpoint(os.path.join(wdir, "best.ckpt"), fresh)
     for (k, a), (_, b) in zip(fresh.state_dict().items(), model.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
     # the model is back in training mode with unfolded weights after every validation pass
     assert model.training
+    # the test epoch (train.py:239-240) ran on the BEST checkpoint: macro F1 in [0, 1], a confusion matrix of the test labels
+    f1, cm = train.run.test_result
+    assert 0.0 <= f1 <= 1.0 and cm.shape == (19, 19) and int(cm.sum()) == 2
+    import numpy as np
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "gelans_32x32_t", "confusion_matrix.npy")), cm)
+    assert os.path.getsize(os.path.join(str(tmp_path), "gelans_32x32_t", "confusion_matrix.npy")) > 0
 
 
 @pytest.mark.gpu
