@@ -73,6 +73,7 @@ struct WgradArgs {
     int win;                      // 1: 3x3 stride-1 window kernel (wgrad3_kernel); 2: kernel-row tiles (wgrad_row3_kernel)
     unsigned y_bytes, x_bytes;    // filled by mtn_wgrad_run: byte extents of dY / X (buffer descriptors)
     unsigned magic_ow, magic_oh;  // filled by mtn_wgrad_run: multiply-high divisors of the pixel walk
+    int slab_bf16;                // filled by mtn_wgrad_run: the partial tiles are stored as bf16 (bf16 mode only)
 };
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);
@@ -106,6 +107,7 @@ int mtn_bn_bwd_blocks(int M);
 void mtn_bn_set_fwd_order(int descending);
 void mtn_bn_set_ticket(int on);
 void mtn_wgrad_set_skip_reduce(int on);
+void mtn_wgrad_set_slab_bf16(int on);
 int mtn_bn_bwd_run(const BnBwdArgs& a, int dtype, hipStream_t stream);
 int mtn_colsum_run(float* slab, int rows, int W, float* out, hipStream_t stream);
 int mtn_colsum_ld_run(float* slab, int rows, int W, int ld, float* out, hipStream_t stream);

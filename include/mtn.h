@@ -132,7 +132,10 @@ int mtn_linear_fwd(const void* x, int ldx, const void* w, const float* bias, int
 
 /* ---- weight gradients (autograd of the Conv2d / Linear sites above) ----------------------------
  * dw is written (not accumulated) in the reference layout: Conv2d OIHW [Cout][Cin][k][k],
- * Linear [N][K].  x is the forward input (NHWC), dy the gradient of the raw conv output. */
+ * Linear [N][K].  x is the forward input (NHWC), dy the gradient of the raw conv output.
+ * The pixel axis is split over workgroups; each writes its f32-accumulated partial tile to the workspace and a second
+ * launch sums the splits in f32 in a fixed order.  MTN_DTYPE_BF16 stores the partial tiles as bf16 (one rounding of an
+ * f32 sum, the precision class of a bf16 autocast weight gradient); F32 / F32X3 store them as f32. */
 size_t mtn_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
                                       int stride);
 int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
@@ -320,7 +323,8 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  *          halves, weights through registers, 256x128 tiles: DESIGN.md section 7d); keys 19 / 20: split-bf16 tile /
  *          LDS-stage variants; key 21 = retired (accepted, no effect); key 22 = persistent pointwise kernel (0 off,
  *          2: also K = 512); key 24 = channel-chunk order of bn_act_fwd; key 25 = bands per image of the pose-head
- *          backward (0 = by batch size); keys 26 / 27 = measured-and-rejected tail variants (experiments builds: profiles/r04_tail_ab.txt).
+ *          backward (0 = by batch size); keys 26 / 27 = measured-and-rejected tail variants (experiments builds: profiles/r04_tail_ab.txt);
+ *          key 28 = 0: f32 partial tiles in the split-K workspace of the bf16 mode (default: bf16 tiles, summed in f32).
  * Every key is refused (MTN_ERR_UNSUPPORTED, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
  * call into the library: the product path has no mutable configuration.
  * The environment variable MTN_DEBUG_KEYS="k=v,k=v" applies keys when the binding loads the library.

@@ -299,6 +299,32 @@ def test_conv_wgrad(be, dtype, tr16, cfg):
     assert rel_err(dw, w.grad) < tol(dtype, 1e-4, 1e-2)
 
 
+@pytest.mark.parametrize("cfg", [(2, 6, 6, 64, 64, 3, 1), (3, 5, 7, 128, 128, 1, 1), (1, 8, 8, 64, 128, 3, 2), (1, 20, 30, 64, 64, 1, 1)])
+def test_conv_wgrad_bf16_slab(be, cfg):
+    """The split-K partial tiles of the bf16 mode are stored as bf16 and summed in f32 (debug key 28 = 0: f32 tiles): within the
+    mode's own tolerance of torch, and within bf16 rounding of the f32-slab result."""
+    B, H, W, Cin, Cout, k, s = cfg
+    dtype = torch.bfloat16
+    x = _rand((B, H, W, Cin), dtype, 12)
+    w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    yref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, k // 2)
+    dy = _rand(tuple(yref.permute(0, 2, 3, 1).shape), dtype, 13)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    got = []
+    for key in (0, 1):
+        dbg(28, key)
+        try:
+            ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, k, s) // 4, device=be.device)
+            dw = torch.full((Cout, Cin, k, k), float("nan"), device=be.device)
+            ops.conv_wgrad(x.to(be.device), dy.to(be.device), dw, ws, k, s)
+            be.sync()
+        finally:
+            dbg(28, 1)
+        assert rel_err(dw, w.grad) < 1e-2
+        got.append(dw.cpu())
+    assert rel_err(got[1], got[0]) < 4e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [
     # B, H, W, Cout, stride   (3x3, Cin = 64)
@@ -321,6 +347,7 @@ def test_conv_wgrad_kernel_row_tiles(be, dtype, cfg):
     outs = []
     for row3 in (1, 0):
         dbg(18, row3)
+        dbg(28, 0)            # (two kernels are compared to 1e-5: f32 partial tiles for both)
         try:
             ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, k, s) // 4, dtype=torch.float32, device=be.device)
             dw = torch.full((Cout, Cin, k, k), float("nan"), device=be.device)
@@ -328,6 +355,7 @@ def test_conv_wgrad_kernel_row_tiles(be, dtype, cfg):
             be.sync()
         finally:
             dbg(18, 1)
+            dbg(28, 1)
         assert rel_err(dw, w.grad) < tol(dtype, 1e-4, 1e-2)
         outs.append(dw.clone())
     assert rel_err(outs[0], outs[1]) < 1e-5
@@ -354,6 +382,7 @@ def test_conv_wgrad_window_kernel(be, dtype, cfg):
     for win in (1, 0):
         dbg(13, win)
         dbg(10, slots if win else 0)
+        dbg(28, 0)            # (two kernels are compared to 1e-5: f32 partial tiles for both)
         try:
             ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 3, 1) // 4, device=be.device)
             dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=be.device)
@@ -363,6 +392,7 @@ def test_conv_wgrad_window_kernel(be, dtype, cfg):
         finally:
             dbg(13, 1)
             dbg(10, 0)
+            dbg(28, 1)
     assert rel_err(res[0], w.grad) < tol(dtype, 1e-4, 1e-2)
     assert rel_err(res[0], res[1]) < tol(dtype, 1e-5, 1e-5)       # same products, f32 sums in another order
 
