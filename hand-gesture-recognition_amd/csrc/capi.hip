@@ -232,6 +232,10 @@ int mtn_conv1_bn_act(const float* x_nchw, const void* w, const float* scale_shif
                      int H, int W, void* stream) {
     return mtn_conv1_bn_act_run(x_nchw, w, scale_shift, out, act, dtype, B, H, W, (hipStream_t)stream);
 }
+int mtn_conv1_dx(const float* x_nchw, const float* w_oihw, const void* dout, const float* scale_shift, const float* mean_rstd,
+                 const float* dgamma, const float* dbeta, float* dx_nchw, int act, int dtype, int B, int H, int W, void* stream) {
+    return mtn_conv1_dx_run(x_nchw, w_oihw, dout, scale_shift, mean_rstd, dgamma, dbeta, dx_nchw, act, dtype, B, H, W, (hipStream_t)stream);
+}
 int mtn_conv1_bwd_partial_rows(int B, int H, int W) {
     const int blocks = mtn_conv1_bwd_blocks((long)B * (H / 2) * (W / 2));
     // producer rows (+ the column-sum scratch the library appends) + one row for the sums themselves

@@ -476,6 +476,93 @@ __global__ __launch_bounds__(256) void conv1_bwd_finalize_kernel(const float* __
     }
 }
 
+
+// ---- gradient of the IMAGE through the stem (autograd parity; not part of the training step) ----------------------
+// MultiTaskNet is a plain autograd module in the reference (model/multitasknet.py:24-29): x.grad exists when the caller asks
+// for it.  The training step never does, so the fused backward above produces no d raw tensor; this kernel recomputes it for
+// its own tile and scatters it back through the 3 x 3 / stride-2 taps as a gather:
+//   phase 1  work item = (output pixel of the tile's halo, 16 channels): raw = W a (fp32 VALU on the fp32 master weights),
+//            z = raw scale + shift, dz = g silu'(z), d raw = scale (dz - m1 - xhat m2)  (m1 = dbeta / M, m2 = dgamma / M:
+//            the sums the fused backward left in the BatchNorm gradients)                       -> LDS [pixels][64] f32
+//   phase 2  thread = input pixel: dx[c] = sum over its <= 4 output pixels and 64 channels of d raw * W[o][c][ky][kx]
+// A tile is 16 x 32 input pixels (9 x 17 output pixels).  One writer per dx element: deterministic.
+constexpr int DX_TH = 16, DX_TW = 32, DX_OH = DX_TH / 2 + 1, DX_OW = DX_TW / 2 + 1, DX_OP = DX_OH * DX_OW;
+template <class S, bool SILU>
+__global__ __launch_bounds__(256) void conv1_dx_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const S* __restrict__ dact, const float* __restrict__ ss,
+                                                       const float* __restrict__ mr, const float* __restrict__ dgamma,
+                                                       const float* __restrict__ dbeta, float* __restrict__ dx, int B, int H,
+                                                       int W, float inv_count) {
+    __shared__ float sW[CO * KK];                 // [o][c*9 + ky*3 + kx]  (OIHW as stored)
+    __shared__ float sK[6][CO];                   // scale, shift, mean, rstd, m1, m2
+    __shared__ float sD[DX_OP][CO + 1];           // d raw of the tile's output pixels (+1: conflict-free column walks)
+    const int tid = threadIdx.x;
+    const int OH = H / 2, OW = W / 2;
+    const int tiles_x = (W + DX_TW - 1) / DX_TW, tiles_y = (H + DX_TH - 1) / DX_TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int iy0 = ty * DX_TH, ix0 = tx * DX_TW, oy0 = iy0 / 2, ox0 = ix0 / 2;
+    for (int i = tid; i < CO * KK; i += 256) sW[i] = w[i];
+    if (tid < CO) {
+        sK[0][tid] = ss[tid]; sK[1][tid] = ss[CO + tid]; sK[2][tid] = mr[tid]; sK[3][tid] = mr[CO + tid];
+        sK[4][tid] = dbeta[tid] * inv_count; sK[5][tid] = dgamma[tid] * inv_count;
+    }
+    __syncthreads();
+    const float* xb = x + (long)b * 3 * H * W;
+    for (int it = tid; it < DX_OP * 4; it += 256) {
+        const int p = it >> 2, q = it & 3;
+        const int oy = oy0 + p / DX_OW, ox = ox0 + p % DX_OW;
+        const bool ok = oy < OH && ox < OW;
+        float a[KK];
+        MTN_UNROLL for (int c = 0; c < 3; ++c)
+            MTN_UNROLL for (int ky = 0; ky < 3; ++ky)
+                MTN_UNROLL for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                    a[c * 9 + ky * 3 + kx] = (ok && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((long)c * H + iy) * W + ix] : 0.f;
+                }
+        float g[16];
+        if (ok) {
+            const S* gp = dact + (((long)b * OH + oy) * OW + ox) * CO;
+            MTN_UNROLL for (int e = 0; e < 16; e += Ev<S>::N) ld_vec<S>(gp, q * 16 + e, g + e);
+        }
+        for (int j = 0; j < 16; ++j) {
+            const int o = q * 16 + j;
+            float raw = 0.f;
+            MTN_UNROLL for (int k = 0; k < KK; ++k) raw += sW[o * KK + k] * a[k];
+            const float z = raw * sK[0][o] + sK[1][o];
+            float dz = ok ? g[j] : 0.f;
+            if (SILU) {
+                const float sg = 1.f / (1.f + __expf(-z));
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            const float xh = (raw - sK[2][o]) * sK[3][o];
+            sD[p][o] = ok ? sK[0][o] * (dz - sK[4][o] - xh * sK[5][o]) : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < DX_TH * DX_TW; i += 256) {
+        const int iy = iy0 + i / DX_TW, ix = ix0 + i % DX_TW;
+        if (iy >= H || ix >= W) continue;
+        float acc[3] = {0.f, 0.f, 0.f};
+        MTN_UNROLL for (int ky = 0; ky < 3; ++ky) {
+            const int ny = iy + 1 - ky;                       // = 2 oy
+            if (ny < 0 || (ny & 1) || ny / 2 >= OH) continue;
+            MTN_UNROLL for (int kx = 0; kx < 3; ++kx) {
+                const int nx = ix + 1 - kx;
+                if (nx < 0 || (nx & 1) || nx / 2 >= OW) continue;
+                const float* d = sD[(ny / 2 - oy0) * DX_OW + (nx / 2 - ox0)];
+                for (int o = 0; o < CO; ++o) {
+                    const float v = d[o];
+                    MTN_UNROLL for (int c = 0; c < 3; ++c) acc[c] += v * sW[o * KK + c * 9 + ky * 3 + kx];
+                }
+            }
+        }
+        MTN_UNROLL for (int c = 0; c < 3; ++c) dx[(((long)b * 3 + c) * H + iy) * W + ix] = acc[c];
+    }
+}
+
 }  // namespace
 
 int mtn_conv1_tiles(long M) { return (int)((M + PXB - 1) / PXB); }
@@ -612,4 +699,27 @@ int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const flo
         MTN_LAUNCH(conv1_bwd_finalize_kernel<float>, dim3(1), dim3(256), 0, stream, (const float*)sums, (const float*)w, scale_shift,
                    mean_rstd, (double)M, dgamma, dbeta, dw);
     return mtn_check_launch("conv1_bwd_finalize");
+}
+
+// dx f32 NCHW [B][3][H][W] (overwritten).  w: the fp32 MASTER weights OIHW [64][3][3][3]; dact: gradient of the stem's activation
+// (NHWC, the mode's storage); dgamma / dbeta: as left by mtn_conv1_bwd_run for the same (x, dact).
+int mtn_conv1_dx_run(const float* x, const float* w, const void* dact, const float* scale_shift, const float* mean_rstd,
+                     const float* dgamma, const float* dbeta, float* dx, int act, int dtype, int B, int H, int W, hipStream_t stream) {
+    MTN_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv1_dx: bad geometry");
+    MTN_REQUIRE(x && w && dact && scale_shift && mean_rstd && dgamma && dbeta && dx, "conv1_dx: null operand");
+    MTN_REQUIRE(act == MTN_ACT_NONE || act == MTN_ACT_SILU, "conv1_dx: act=%d", act);
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "conv1_dx: bad dtype %d", dtype);
+    MTN_REQUIRE((uintptr_t)dact % 16 == 0, "conv1_dx: dact must be 16-byte aligned");
+    const long tiles = (long)B * ((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW);
+    MTN_REQUIRE(tiles < (1L << 31), "conv1_dx: too many tiles");
+    const float inv = 1.0f / (float)((long)B * (H / 2) * (W / 2));
+#define MTN_CONV1_DX(S, SILU) \
+    MTN_LAUNCH((conv1_dx_kernel<S, SILU>), dim3((unsigned)tiles), dim3(256), 0, stream, x, w, (const S*)dact, scale_shift, mean_rstd, \
+               dgamma, dbeta, dx, B, H, W, inv)
+    const bool silu = act == MTN_ACT_SILU;
+    if (dtype == MTN_BF16) { if (silu) MTN_CONV1_DX(bf16_t, true); else MTN_CONV1_DX(bf16_t, false); }
+    else if (dtype == MTN_F32X3) { if (silu) MTN_CONV1_DX(f32x3_t, true); else MTN_CONV1_DX(f32x3_t, false); }
+    else { if (silu) MTN_CONV1_DX(float, true); else MTN_CONV1_DX(float, false); }
+#undef MTN_CONV1_DX
+    return mtn_check_launch("conv1_dx");
 }

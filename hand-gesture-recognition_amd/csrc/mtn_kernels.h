@@ -128,6 +128,8 @@ int mtn_conv1_bwd_width(void);
 int mtn_conv1_bwd_run(const float* x, const void* w, const void* dout, const float* scale_shift, const float* mean_rstd,
                       float* partial, float* dgamma, float* dbeta, float* dw, int act, int dtype, int B, int H, int W,
                       hipStream_t stream);
+int mtn_conv1_dx_run(const float* x, const float* w, const void* dact, const float* scale_shift, const float* mean_rstd,
+                     const float* dgamma, const float* dbeta, float* dx, int act, int dtype, int B, int H, int W, hipStream_t stream);
 int mtn_conv1_wgrad_run(const float* x, const void* dy, float* dw, float* partial, int dtype, int B, int H, int W,
                         hipStream_t stream);
 

@@ -499,10 +499,17 @@ class Engine:
         u1, bn = self.u_conv1, self.u_conv1.mod.bn
         self.o.conv1_bwd(self.x_in, u1.wf, self.g_a1, u1.ss, u1.mr, self.conv1_part, self._g(bn.weight), self._g(bn.bias),
                       self._g(u1.weight), _ACT[u1.act])
+        if getattr(self, "_dx", None) is not None:
+            self.o.conv1_dx(self.x_in, u1.weight.detach(), self.g_a1, u1.ss, u1.mr, self._g(bn.weight), self._g(bn.bias), self._dx,
+                         _ACT[u1.act])
+            self._dx = None
         self._ready("stem")
 
-    def backward(self, dlogits=None, dhm=None):
-        """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written."""
+    def backward(self, dlogits=None, dhm=None, dx=None):
+        """Backward of forward() from gradients of (logits, heatmaps); all parameter grads written.  ``dx`` (fp32, shaped like
+        the image): also the gradient of the image -- the reference module is plain autograd (multitasknet.py:24-29); the
+        training step never asks for it."""
+        self._dx = dx
         self.check_current()
         dlogits = self.dlogits if dlogits is None else dlogits
         dhm = self.dhm if dhm is None else dhm

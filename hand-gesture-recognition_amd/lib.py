@@ -38,6 +38,7 @@ _PROTOS = {
     "mtn_conv1_bwd_partial_rows": [_i, _i, _i],
     "mtn_conv1_bwd_partial_width": [],
     "mtn_conv1_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mtn_conv1_dx": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_slab_rows": [_i],
     "mtn_bn_finalize": [_vp, _i, _i, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp],
     "mtn_bn_eval_scale_shift": [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp],

@@ -10,7 +10,8 @@ Deviations from the reference module, all deliberate:
   * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174); like the other two
     outputs it is a fresh tensor per call (a 172 MB copy at B = 256 / 145 tokens: ``share_attnmap = True`` hands out the
     plan's own buffer instead, which the next forward overwrites -- ``TrainStep`` never copies);
-  * the input gets no gradient (``x.grad`` stays None: nothing in the reference's training or export paths asks for it);
+  * (since round 4 the image gets its gradient when it requires one, like the reference's plain autograd module -- a separate
+    stem kernel, not part of the training step);
   * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode),
     fp32 storage / exact-f32 MFMA (validation mode), or "bf16x3": fp32 storage with split-bf16 matrix
     products (three MFMAs per product).  Both fp32-storage modes keep logits / heat-maps / attention map within 1e-3 of the
@@ -63,9 +64,10 @@ class _PlanFunction(torch.autograd.Function):
         eng = ctx.engine
         dlogits = torch.zeros_like(eng.logits) if dlogits is None else dlogits.contiguous()
         dhm = torch.zeros_like(eng.hm) if dhm is None else dhm.contiguous()
-        eng.backward(dlogits, dhm)
+        dx = torch.empty_like(eng.x_in) if ctx.needs_input_grad[1] else None
+        eng.backward(dlogits, dhm, dx=dx)
         ctx.model.publish_grads()
-        return torch.zeros(1, device=dlogits.device), None, None, None
+        return torch.zeros(1, device=dlogits.device), dx, None, None
 
 
 class MultiTaskNet(nn.Module):

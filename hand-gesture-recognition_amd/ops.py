@@ -319,6 +319,18 @@ def conv1_bwd(x_nchw, w, dout, scale_shift, mean_rstd, partial, dgamma, dbeta, d
              dtype_code(dout, mode), B, H, W, _stream(dout))
 
 
+def conv1_dx(x_nchw, w_oihw, dout, scale_shift, mean_rstd, dgamma, dbeta, dx, act, mode=None):
+    """gradient of the image through the stem (after conv1_bwd of the same pass): dx f32 NCHW, overwritten."""
+    B, _, H, W = x_nchw.shape
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and dout.is_contiguous()
+    assert dx.dtype == torch.float32 and dx.is_contiguous() and tuple(dx.shape) == tuple(x_nchw.shape)
+    assert w_oihw.dtype == torch.float32 and w_oihw.is_contiguous() and tuple(w_oihw.shape) == (64, 3, 3, 3)
+    assert tuple(dout.shape) == (B, H // 2, W // 2, 64)
+    lib.call("mtn_conv1_dx", x_nchw.data_ptr(), w_oihw.data_ptr(), dout.data_ptr(), scale_shift.data_ptr(),
+             mean_rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), act, dtype_code(dout, mode),
+             B, H, W, _stream(dout))
+
+
 # ---- ViT encoder --------------------------------------------------------------------------------
 def tokens_fwd(feat, pos, cls, tok, mode=None):
     """feat [B*P,256] (+pos f32 [P,256]) and cls f32 [256] -> tok [B,P+1,256]."""

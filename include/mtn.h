@@ -123,6 +123,12 @@ int mtn_conv1_bwd_partial_width(void);
 int mtn_conv1_bwd(const float* x_nchw, const void* w, const void* dout, const float* scale_shift,
                   const float* mean_rstd, float* partial, float* dgamma, float* dbeta, float* dw,
                   int act, int dtype, int B, int H, int W, void* stream);
+/* Gradient of the IMAGE through the stem (autograd parity with the reference's plain module, multitasknet.py:24-29; the
+ * training step never asks for it): dx f32 NCHW [B][3][H][W], overwritten.  w_oihw: the fp32 master weights [64][3][3][3];
+ * dout / scale_shift / mean_rstd as for mtn_conv1_bwd; dgamma / dbeta [64]: what mtn_conv1_bwd wrote for the same (x, dout). */
+int mtn_conv1_dx(const float* x_nchw, const float* w_oihw, const void* dout, const float* scale_shift,
+                 const float* mean_rstd, const float* dgamma, const float* dbeta, float* dx_nchw, int act, int dtype,
+                 int B, int H, int W, void* stream);
 
 /* ---- nn.Linear / 1x1 projections  (model/transformer.py:34-37,56-58; multitasknet.py:13) ------
  * out = act(x @ w^T + bias) + res ; w is [N][K]; aux_out (optional) gets the pre-activation. */

@@ -185,3 +185,46 @@ def test_outputs_are_fresh_tensors_per_call():
     m.share_attnmap = True
     first = m(b0[0])
     assert first[2].data_ptr() == m.engine(2).attn.data_ptr()
+
+
+def _image_grad_case(be, dtype, tol, size=32, B=2):
+    sd = O.synthetic_state_dict(21, 19, seed=9)
+    img, label, target, tw = O.synthetic_batch(B, size, seed=23)
+    # oracle: the reference's arithmetic with the image as a leaf
+    osd = {k: v.clone() for k, v in sd.items()}
+    xo = img.clone().requires_grad_(True)
+    cls_o, hm_o, _ = O.multitasknet_forward(xo, osd, training=True)
+    tot_o, _, _ = O.total_loss(cls_o, hm_o, label, target, tw)
+    tot_o.backward()
+    m = MultiTaskNet(21, 19, [size, size], compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m.to(be.device).train()
+    x = img.clone().to(be.device).requires_grad_(True)
+    cls_out, hmap, _ = m(x)
+    tot, _, _ = O.total_loss(cls_out, hmap, label.to(be.device), target.to(be.device), tw.to(be.device))
+    tot.backward()
+    assert x.grad is not None and x.grad.shape == x.shape and x.grad.dtype == torch.float32
+    err = rel_err(x.grad, xo.grad)
+    assert err < tol, err
+    # a second pass WITHOUT an image gradient must not touch the previous one or produce one
+    x2 = img.clone().to(be.device)
+    c2, h2, _ = m(x2)
+    O.total_loss(c2, h2, label.to(be.device), target.to(be.device), tw.to(be.device))[0].backward()
+    assert x2.grad is None
+    return err
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), ("bf16x3", 3e-2), (torch.bfloat16, 0.15)])
+def test_image_gradient_like_the_autograd_module(dtype, tol):
+    """The reference is a plain autograd module (multitasknet.py:24-29): an image that requires a gradient gets one.  The stem's
+    data gradient (conv1_dx_kernel) against the oracle's autograd; the bounds are the parameter-gradient bounds of the same
+    case and mode in tests/test_model_parity.py (tiny 32x32 images: BatchNorm over 8 samples in stage 3 amplifies the split-bf16
+    product error to ~1e-2; bf16: GRAD_NOISE)."""
+    _image_grad_case(Backend("emu"), dtype, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol,size,B", [(torch.float32, 1e-3, 64, 3), ("bf16x3", 1e-2, 64, 3), ("bf16x3", 2.5e-3, 192, 4),
+                                              (torch.bfloat16, 0.15, 192, 4)])
+def test_image_gradient_gpu(dtype, tol, size, B):
+    _image_grad_case(Backend("hip"), dtype, tol, size=size, B=B)
