@@ -176,6 +176,11 @@ class MultiTaskNet(nn.Module):
             for p in params:
                 p._mtn_acc = self._grad_acc[off:off + p.numel()].view(p.shape)
                 off += p.numel()
+        # a frozen parameter (requires_grad False) keeps p.grad = None, as under autograd (its segment of the buffers is computed
+        # by the plan anyway and simply not handed out: clip_grad_norm_ / optimizers see what they would see with the reference)
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            return
         # fresh: this parameter's p.grad is not (yet) our accumulation view -- None, or a tensor somebody else put there
         fresh = [p.grad is None or p.grad.data_ptr() != p._mtn_acc.data_ptr() for p in params]
         with torch.no_grad():

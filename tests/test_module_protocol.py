@@ -228,3 +228,30 @@ def test_image_gradient_like_the_autograd_module(dtype, tol):
                                               (torch.bfloat16, 0.15, 192, 4)])
 def test_image_gradient_gpu(dtype, tol, size, B):
     _image_grad_case(Backend("hip"), dtype, tol, size=size, B=B)
+
+
+def test_frozen_parameters_get_no_grad():
+    """requires_grad_(False) on a sub-module (a frozen backbone): those parameters keep p.grad None, the others accumulate."""
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=10)
+    batch = O.synthetic_batch(2, 32, seed=31)
+    m = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    ref = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    ref.load_state_dict(sd, strict=True)
+    _, g_all = _fwd_bwd(ref, batch)
+    m.encoder.requires_grad_(False)
+    img, label, target, tw = batch
+    cls_out, hmap, _ = m(img)
+    O.total_loss(cls_out, hmap, label, target, tw)[0].backward()
+    assert all(p.grad is None for p in m.encoder.parameters())
+    got = torch.cat([p.grad.flatten() for p in m.parameters() if p.requires_grad])
+    want = torch.cat([q.grad.flatten() for (n, q) in ref.named_parameters() if not n.startswith("encoder.")])
+    assert torch.equal(got, want)
+    m.encoder.requires_grad_(True)                       # unfrozen again: the next backward hands the gradients out
+    cls_out, hmap, _ = m(img)
+    O.total_loss(cls_out, hmap, label, target, tw)[0].backward()
+    assert all(p.grad is not None for p in m.encoder.parameters())
+    enc = torch.cat([p.grad.flatten() for p in m.encoder.parameters()])
+    enc_ref = torch.cat([q.grad.flatten() for (n, q) in ref.named_parameters() if n.startswith("encoder.")])
+    assert torch.equal(enc, enc_ref)
