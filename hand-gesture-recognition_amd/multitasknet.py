@@ -10,8 +10,10 @@ Deviations from the reference module, all deliberate:
   * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174); like the other two
     outputs it is a fresh tensor per call (a 172 MB copy at B = 256 / 145 tokens: ``share_attnmap = True`` hands out the
     plan's own buffer instead, which the next forward overwrites -- ``TrainStep`` never copies);
-  * (since round 4 the image gets its gradient when it requires one, like the reference's plain autograd module -- a separate
-    stem kernel, not part of the training step);
+  * (since round 4 the module is an ordinary autograd citizen otherwise: the image gets its gradient when it requires one -- a
+    separate stem kernel, not part of the training step --, parameter gradients arrive through autograd's own accumulation
+    nodes: hooks, ``requires_grad_(False)``, ``torch.autograd.grad`` and a ``DistributedDataParallel`` wrapper work; a
+    backward in ``eval()`` mode is not offered: the BatchNorms are folded into the weights there);
   * ``compute_dtype``: bf16 storage / bf16 MFMA with fp32 accumulation (default, throughput mode),
     fp32 storage / exact-f32 MFMA (validation mode), or "bf16x3": fp32 storage with split-bf16 matrix
     products (three MFMAs per product).  Both fp32-storage modes keep logits / heat-maps / attention map within 1e-3 of the
@@ -49,25 +51,38 @@ def resolve_compute_dtype(compute_dtype):
 
 
 class _PlanFunction(torch.autograd.Function):
-    """Connects Engine.forward/backward to autograd (one node for the whole network)."""
+    """Connects Engine.forward/backward to autograd: ONE node for the whole network whose inputs are the image and every
+    parameter, so that autograd itself delivers the gradients -- its per-parameter accumulation nodes set / add ``p.grad``
+    (``accumulate_grad_batches``, both forms of ``zero_grad``), call parameter hooks (``register_hook``, the reducer of a
+    ``DistributedDataParallel`` wrapper), honour ``requires_grad_(False)`` and serve ``torch.autograd.grad``: the module
+    behaves like the reference's plain autograd module (model/multitasknet.py:24-29).  The parameter tensors themselves
+    are not read here: the plan reads the flat buffer they are views of."""
 
     @staticmethod
-    def forward(ctx, anchor, x, model, engine):
+    def forward(ctx, x, model, engine, *params):
         logits, hm, attn = engine.forward(x, training=model.training)
         ctx.model, ctx.engine = model, engine
+        ctx.shapes = [p.shape for p in params]
         attn = attn if model.share_attnmap else attn.clone()
         ctx.mark_non_differentiable(attn)
         return logits.clone(), hm.clone(), attn
 
     @staticmethod
     def backward(ctx, dlogits, dhm, _dattn):
-        eng = ctx.engine
+        eng, model = ctx.engine, ctx.model
         dlogits = torch.zeros_like(eng.logits) if dlogits is None else dlogits.contiguous()
         dhm = torch.zeros_like(eng.hm) if dhm is None else dhm.contiguous()
-        dx = torch.empty_like(eng.x_in) if ctx.needs_input_grad[1] else None
+        dx = torch.empty_like(eng.x_in) if ctx.needs_input_grad[0] else None
         eng.backward(dlogits, dhm, dx=dx)
-        ctx.model.publish_grads()
-        return torch.zeros(1, device=dlogits.device), dx, None, None
+        # this backward's gradients in a buffer of their own (the plan's buffer is overwritten by the next backward): the
+        # accumulation nodes keep these views as p.grad or add them to the p.grad that is there
+        g = model.flat_grads.clone()
+        outs, off = [], 0
+        for i, shape in enumerate(ctx.shapes):
+            k = shape.numel()
+            outs.append(g[off:off + k].view(shape) if ctx.needs_input_grad[3 + i] else None)
+            off += k
+        return (dx, None, None, *outs)
 
 
 class MultiTaskNet(nn.Module):
@@ -94,7 +109,6 @@ class MultiTaskNet(nn.Module):
         self.compute_dtype = compute_dtype
         self.share_attnmap = False          # True: forward() returns the plan's attention-map buffer itself (no copy)
         self._engines = {}
-        self._anchor = None
         self._generation = 0
         self._flatten()
 
@@ -116,12 +130,10 @@ class MultiTaskNet(nn.Module):
                 p.grad = None
                 off += k
         self.flat_params, self.flat_grads, self.n_params = flat, grads, n
-        self._grad_acc = None                     # what p.grad views (autograd semantics: backward ADDS into it), lazily
         # every re-flatten orphans the buffers that existing plans (Engine) and optimizers (TrainStep)
         # captured: they compare this counter with the one they were built at and refuse to run stale
         self._generation = getattr(self, "_generation", 0) + 1
         self._engines = {}
-        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
 
     def _views_ok(self):
         """True iff every parameter is still a view of ``flat_params`` at its offset and owns a
@@ -140,7 +152,7 @@ class MultiTaskNet(nn.Module):
         parameters alias ITS flat_params (fused AdamW / all-reduce operate on the flat buffer)."""
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
-        skip = ("flat_params", "flat_grads", "_anchor", "_engines", "_grad_acc")
+        skip = ("flat_params", "flat_grads", "_engines")
         for k, v in self.__dict__.items():
             if k not in skip:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -158,45 +170,6 @@ class MultiTaskNet(nn.Module):
         super()._apply(fn, *args, **kwargs)       # .to() / .cuda() / .float(): params get new storage
         self._flatten()
         return self
-
-    def publish_grads(self):
-        """Give ``p.grad`` autograd's semantics after a ``loss.backward()`` through this module: the gradient of THIS
-        backward (the plan wrote it into ``flat_grads``) is ADDED to ``p.grad`` where one exists and becomes ``p.grad``
-        where it is None -- so ``accumulate_grad_batches``, two losses backpropagated in turn, and both forms of
-        ``zero_grad`` behave as with the reference module (model/multitasknet.py is a plain autograd module).
-        ``p.grad`` tensors are views of one flat accumulation buffer: the whole update is one ``add_`` / ``copy_`` in the
-        common cases.  (The fused ``TrainStep`` does not come through here: it consumes ``flat_grads`` directly.)"""
-        if not self._views_ok():
-            raise RuntimeError("MultiTaskNet parameters no longer alias flat_params (their storage was replaced after "
-                               "the plan was built); call model._flatten() and rebuild the TrainStep")
-        params = list(self.parameters())
-        if self._grad_acc is None or self._grad_acc.device != self.flat_grads.device:
-            self._grad_acc = torch.zeros_like(self.flat_grads)
-            off = 0
-            for p in params:
-                p._mtn_acc = self._grad_acc[off:off + p.numel()].view(p.shape)
-                off += p.numel()
-        # a frozen parameter (requires_grad False) keeps p.grad = None, as under autograd (its segment of the buffers is computed
-        # by the plan anyway and simply not handed out: clip_grad_norm_ / optimizers see what they would see with the reference)
-        params = [p for p in params if p.requires_grad]
-        if not params:
-            return
-        # fresh: this parameter's p.grad is not (yet) our accumulation view -- None, or a tensor somebody else put there
-        fresh = [p.grad is None or p.grad.data_ptr() != p._mtn_acc.data_ptr() for p in params]
-        with torch.no_grad():
-            if not any(fresh):                               # accumulate (zero_grad(set_to_none=False) zeroed the views in place)
-                self._grad_acc.add_(self.flat_grads)
-                return
-            foreign = [p.grad if f else None for p, f in zip(params, fresh)]
-            if all(fresh):                                   # first backward / after zero_grad(set_to_none=True)
-                self._grad_acc.copy_(self.flat_grads)
-            else:                                            # mixed: per parameter
-                for p, f in zip(params, fresh):
-                    (p._mtn_acc.copy_ if f else p._mtn_acc.add_)(p._mtn_grad)
-            for p, g in zip(params, foreign):
-                if g is not None:
-                    p._mtn_acc.add_(g)                       # a gradient that was already there still counts
-                p.grad = p._mtn_acc
 
     def set_compute_dtype(self, dtype):
         if isinstance(dtype, str):
@@ -228,6 +201,6 @@ class MultiTaskNet(nn.Module):
         x = x.to(torch.float32).contiguous()
         eng = self.engine(x.shape[0])
         if torch.is_grad_enabled() and self.training:
-            return _PlanFunction.apply(self._anchor, x, self, eng)
+            return _PlanFunction.apply(x, self, eng, *self.parameters())
         logits, hm, attn = eng.forward(x, training=self.training)
         return logits.clone(), hm.clone(), (attn if self.share_attnmap else attn.clone())

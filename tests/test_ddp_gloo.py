@@ -79,6 +79,58 @@ def test_ddp_two_ranks_gloo():
     assert float((sd["w"] - r0["p1"]).abs().max()) < 1e-6
 
 
+def _ddp_wrapper_worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mtn_oracle as O
+    from backend import Backend
+    from hand_gesture_recognition_amd.multitasknet import MultiTaskNet
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=5)
+    model = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    model.load_state_dict(sd, strict=True)
+    ddp = torch.nn.parallel.DistributedDataParallel(model)      # the wrapper Lightning's multi-device strategies use
+    res = []
+    for it in range(2):                                          # (a second iteration: the reducer finished the first)
+        img, label, target, tw = O.synthetic_batch(2, 32, seed=100 + rank + 10 * it)
+        c, h, _ = ddp(img)
+        model.zero_grad(set_to_none=True)
+        O.total_loss(c, h, label, target, tw)[0].backward()
+        res.append(torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+    # the local gradients of the same batches, for the mean check
+    loc = []
+    for it in range(2):
+        img, label, target, tw = O.synthetic_batch(2, 32, seed=100 + rank + 10 * it)
+        m2 = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+        m2.load_state_dict(sd, strict=True)
+        c, h, _ = m2(img)
+        O.total_loss(c, h, label, target, tw)[0].backward()
+        loc.append(torch.cat([p.grad.flatten() for p in m2.parameters()]).clone())
+    torch.save({"ddp": res, "local": loc}, os.path.join(outdir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_data_parallel_wrapper_gloo():
+    """The module is an ordinary autograd citizen (round 4): wrapped in torch's DistributedDataParallel its gradients are
+    averaged over the ranks by DDP's own reducer hooks, iteration after iteration (BatchNorm statistics stay per rank)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_ddp_wrapper_worker, args=(2, port, d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, "w0.pt")), torch.load(os.path.join(d, "w1.pt"))
+    for it in range(2):
+        assert torch.equal(r0["ddp"][it], r1["ddp"][it])
+        mean = 0.5 * (r0["local"][it] + r1["local"][it])
+        assert torch.allclose(r0["ddp"][it], mean, rtol=1e-5, atol=1e-8), float((r0["ddp"][it] - mean).abs().max())
+        assert not torch.equal(r0["local"][it], r1["local"][it])
+
+
 def _rccl_worker(rank, world, port, outdir):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)

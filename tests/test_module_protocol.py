@@ -255,3 +255,28 @@ def test_frozen_parameters_get_no_grad():
     enc = torch.cat([p.grad.flatten() for p in m.encoder.parameters()])
     enc_ref = torch.cat([q.grad.flatten() for (n, q) in ref.named_parameters() if n.startswith("encoder.")])
     assert torch.equal(enc, enc_ref)
+
+
+def test_parameter_hooks_and_functional_grad():
+    """Parameter gradients arrive through autograd's own accumulation nodes: a hook registered on a parameter is called with
+    its gradient (and may change it), torch.autograd.grad returns the gradients without touching p.grad."""
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=14)
+    img, label, target, tw = O.synthetic_batch(2, 32, seed=33)
+    m = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    _, g_ref = _fwd_bwd(m, (img, label, target, tw))
+    m.zero_grad(set_to_none=True)
+    seen = {}
+    w = m.proj.weight
+    h = w.register_hook(lambda g: seen.setdefault("g", g.clone()) * 2.0)
+    c, hm, _ = m(img)
+    O.total_loss(c, hm, label, target, tw)[0].backward()
+    h.remove()
+    off = sum(p.numel() for p in m.encoder.parameters())
+    want = g_ref[off:off + w.numel()].view_as(w)
+    assert torch.equal(seen["g"], want) and torch.equal(w.grad, 2.0 * want)
+    m.zero_grad(set_to_none=True)
+    c, hm, _ = m(img)
+    gs = torch.autograd.grad(O.total_loss(c, hm, label, target, tw)[0], [m.proj.weight, m.decoder.cls_token])
+    assert torch.equal(gs[0], want) and all(p.grad is None for p in m.parameters())
