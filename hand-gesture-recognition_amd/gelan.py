@@ -102,4 +102,10 @@ class GELANNet(nn.Module):
         return list(zip(blocks, downs))
 
     def forward(self, x):
-        raise RuntimeError("use MultiTaskNet (or engine.Engine.backbone_*) to run the backbone")
+        """gelan.py:165-176.  The backbone runs in the plan of the MultiTaskNet that owns this module (``model.encoder(x)``); a
+        GELANNet constructed on its own has parameters but no plan."""
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            raise RuntimeError("a GELANNet constructed on its own has no execution plan: use it as MultiTaskNet(...).encoder, "
+                               "or engine.Engine.backbone_* directly")
+        return owner.encoder_forward(x)

@@ -85,6 +85,37 @@ class _PlanFunction(torch.autograd.Function):
         return (dx, None, None, *outs)
 
 
+class _BackboneFunction(torch.autograd.Function):
+    """``model.encoder(x)`` on its own (the reference's GELANNet.forward, model/gelan.py:165-176): the backbone part of the plan as
+    one autograd node over the image and the encoder's parameters; NCHW fp32 features like the reference's."""
+
+    @staticmethod
+    def forward(ctx, x, model, engine, *params):
+        engine.check_current()
+        engine.pack_weights()
+        feats = engine.backbone_forward(x, training=True)
+        ctx.model, ctx.engine, ctx.shapes = model, engine, [p.shape for p in params]
+        return engine.features_plain(feats).float().permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        eng, model = ctx.engine, ctx.model
+        eng.check_current()
+        gbuf = eng.stages[-1]["g_out"]
+        eng.set_plain(gbuf, g.permute(0, 2, 3, 1).contiguous().float())
+        dx = torch.empty_like(eng.x_in) if ctx.needs_input_grad[0] else None
+        eng._dx = dx
+        eng.backbone_backward(gbuf)
+        n = sum(s.numel() for s in ctx.shapes)
+        flat = model.flat_grads[:n].clone()                 # (the encoder's parameters come first in parameters() order)
+        outs, off = [], 0
+        for i, shape in enumerate(ctx.shapes):
+            k = shape.numel()
+            outs.append(flat[off:off + k].view(shape) if ctx.needs_input_grad[3 + i] else None)
+            off += k
+        return (dx, None, None, *outs)
+
+
 class MultiTaskNet(nn.Module):
     def __init__(self, num_joints, num_classes, image_size, compute_dtype=None, gelan_type="small", gelan_stages=3):
         super().__init__()
@@ -94,6 +125,7 @@ class MultiTaskNet(nn.Module):
         # reference cannot reach from here.  With four stages the token
         # grid is image_size // 32.
         self.encoder = GELANNet(gelan_type, gelan_stages)                  # multitasknet.py:12
+        object.__setattr__(self.encoder, "_owner", self)                   # (not a sub-module link: encoder(x) runs through this module's plan)
         self.proj = nn.Conv2d(512, 256, 1, bias=False)                     # multitasknet.py:13
         stride = self.encoder.total_stride
         self.decoder = ViT(num_classes=num_classes, num_joints=num_joints,
@@ -193,6 +225,25 @@ class MultiTaskNet(nn.Module):
             self._engines = {key: Engine(self, batch, self.compute_dtype)}    # one live plan at a time
             eng = self._engines[key]
         return eng
+
+    def encoder_forward(self, x):
+        """``self.encoder(x)``: x float32 [B,3,H,W] -> backbone features float32 [B,512,H/16,W/16] (NCHW, like the reference's
+        GELANNet.forward), differentiable in training mode; eval mode runs the folded-BatchNorm kernels without a graph."""
+        if x.dim() != 4 or x.shape[1] != 3 or tuple(x.shape[2:]) != self.image_size:
+            raise ValueError(f"expected [B,3,{self.image_size[0]},{self.image_size[1]}], got {tuple(x.shape)}")
+        x = x.to(torch.float32).contiguous()
+        eng = self.engine(x.shape[0])
+        if torch.is_grad_enabled() and self.training:
+            first = next(self.parameters())
+            assert first is next(self.encoder.parameters()), "the encoder's parameters must lead parameters()"
+            return _BackboneFunction.apply(x, self, eng, *self.encoder.parameters())
+        eng.check_current()
+        if self.training:
+            eng.pack_weights()
+        else:
+            eng.fold_batchnorm()
+        feats = eng.backbone_forward(x, training=self.training)
+        return eng.features_plain(feats).float().permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x):
         """x float32 [B,3,H,W] -> (cls_out [B,classes], hmap_out [B,joints,H/4,W/4], attnmap [B,8,N,N])."""

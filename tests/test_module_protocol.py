@@ -280,3 +280,52 @@ def test_parameter_hooks_and_functional_grad():
     c, hm, _ = m(img)
     gs = torch.autograd.grad(O.total_loss(c, hm, label, target, tw)[0], [m.proj.weight, m.decoder.cls_token])
     assert torch.equal(gs[0], want) and all(p.grad is None for p in m.parameters())
+
+
+def _encoder_case(be, dtype, tol_f, tol_g, size=32, B=2):
+    """model.encoder(x) on its own (gelan.py:165-176): features, the encoder's parameter gradients and the image gradient
+    against the oracle's GELANNet; eval mode without a graph."""
+    sd = O.synthetic_state_dict(21, 19, seed=11)
+    img = O.synthetic_batch(B, size, seed=41)[0]
+    up = torch.randn(B, 512, size // 16, size // 16, generator=torch.Generator().manual_seed(3))
+    sdo = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items() if k.startswith("encoder")}
+    xo = img.clone().requires_grad_(True)
+    ref = O.gelan_net(xo, sdo, training=True)
+    ref.backward(up)
+    m = MultiTaskNet(21, 19, [size, size], compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m.to(be.device).train()
+    x = img.clone().to(be.device).requires_grad_(True)
+    f = m.encoder(x)
+    assert tuple(f.shape) == tuple(ref.shape) and f.dtype == torch.float32
+    assert rel_err(f, ref.detach()) < tol_f
+    f.backward(up.to(be.device))
+    worst = max(rel_err(p.grad, sdo["encoder." + k].grad) for k, p in m.encoder.named_parameters())
+    assert worst < tol_g, worst
+    assert rel_err(x.grad, xo.grad) < tol_g
+    assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("encoder."))
+    # the running statistics moved like the reference's (momentum 0.1)
+    assert rel_err(m.encoder.conv2.bn.running_mean, sdo["encoder.conv2.bn.running_mean"]) < max(tol_f, 1e-4)
+    m.eval()
+    with torch.no_grad():
+        fe = m.encoder(img.to(be.device))
+    sde = {k: v.clone() for k, v in m.state_dict().items() if k.startswith("encoder")}
+    ref_e = O.gelan_net(img, {k: v.cpu() for k, v in sde.items()}, training=False)
+    assert rel_err(fe, ref_e) < tol_f
+
+
+def test_encoder_on_its_own_emu():
+    _encoder_case(Backend("emu"), torch.float32, 1e-3, 1e-3)
+
+
+def test_standalone_gelannet_has_no_plan():
+    from hand_gesture_recognition_amd.gelan import GELANNet
+    with pytest.raises(RuntimeError, match="no execution plan"):
+        GELANNet("small")(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tf,tg", [(torch.float32, 1e-3, 1e-3), ("bf16x3", 1e-3, 1e-2),
+                                         (torch.bfloat16, 1e-1, 0.15)])     # (bf16: 5e-2 at config 5, B = 512; three 64x64 images are noisier)
+def test_encoder_on_its_own_gpu(dtype, tf, tg):
+    _encoder_case(Backend("hip"), dtype, tf, tg, size=64, B=3)
