@@ -405,6 +405,11 @@ class Engine:
         feats = self.backbone_forward(x, training)
         up = self.u_proj
         self.o.conv_fwd(feats, up.wf, up.raw, None, 1, 1)                                   # multitasknet.py:26
+        return self.vit_forward(want_attn)
+
+    def vit_forward(self, want_attn=True):
+        """ViT.forward (model/transformer.py:129-152) on the projected features in ``self.feat`` ([B*P, 256], the plan's
+        storage): -> (logits, heatmaps, attnmap).  The packed weights must be current (pack_weights / fold_batchnorm)."""
         dec = self.model.decoder
         self.o.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                    # transformer.py:132-139
         B, N, D, Hh = self.B, self.N, self.dim, self.heads
@@ -515,6 +520,17 @@ class Engine:
         dhm = self.dhm if dhm is None else dhm
         for u in self.units:
             u.pre_rows = 0          # (a backward that raised half-way must not leave a stale hand-over)
+        self.vit_backward(dlogits, dhm)
+        up, last = self.u_proj, self.stages[-1]
+        gf = self.g_feat.view(self.B, self.fh, self.fw, self.dim)
+        self.o.conv_wgrad(last["out"], gf, self._g(up.weight), self.wgrad_ws, 1, 1)
+        self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
+        self._ready("head")
+        self.backbone_backward(last["g_out"])
+
+    def vit_backward(self, dlogits, dhm):
+        """Backward of vit_forward: the decoder's parameter gradients, and the gradient of the projected features in
+        ``self.g_feat`` ([B*P, 256], the plan's storage)."""
         dec, g = self.model.decoder, self._g
         B, N, D, Hh = self.B, self.N, self.dim, self.heads
         Mt = B * N
@@ -563,14 +579,8 @@ class Engine:
             self.o.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
                               None if defer else self._pair(at.norm.weight, at.norm.bias), dres=Gm)
         self.o.tokens_bwd(G, self.g_feat, g(dec.cls_token))
-        up, last = self.u_proj, self.stages[-1]
-        gf = self.g_feat.view(self.B, self.fh, self.fw, D)
-        self.o.conv_wgrad(last["out"], gf, g(up.weight), self.wgrad_ws, 1, 1)
-        self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
         if self.leaf_plan is not None:
             self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches
-        self._ready("head")
-        self.backbone_backward(last["g_out"])
 
     def _ready(self, tag):
         if self.on_grads_ready is not None:

@@ -116,6 +116,42 @@ class _BackboneFunction(torch.autograd.Function):
         return (dx, None, None, *outs)
 
 
+class _DecoderFunction(torch.autograd.Function):
+    """``model.decoder(feats)`` on its own (the reference's ViT.forward, model/transformer.py:129-152): the ViT part of the plan as one
+    autograd node over the projected features and the decoder's parameters."""
+
+    @staticmethod
+    def forward(ctx, feats, model, engine, first, *params):
+        engine.check_current()
+        engine.pack_weights()
+        engine.set_plain(engine.u_proj.raw, feats.permute(0, 2, 3, 1).contiguous())
+        logits, hm, attn = engine.vit_forward(True)
+        ctx.model, ctx.engine, ctx.first, ctx.shapes = model, engine, first, [p.shape for p in params]
+        attn = attn if model.share_attnmap else attn.clone()
+        ctx.mark_non_differentiable(attn)
+        return logits.clone(), hm.clone(), attn
+
+    @staticmethod
+    def backward(ctx, dlogits, dhm, _dattn):
+        eng, model = ctx.engine, ctx.model
+        eng.check_current()
+        dlogits = torch.zeros_like(eng.logits) if dlogits is None else dlogits.contiguous()
+        dhm = torch.zeros_like(eng.hm) if dhm is None else dhm.contiguous()
+        eng.vit_backward(dlogits, dhm)
+        df = None
+        if ctx.needs_input_grad[0]:
+            gf = eng.g_feat.view(eng.B, eng.fh, eng.fw, eng.dim)
+            df = eng.features_plain(gf).float().permute(0, 3, 1, 2).contiguous()
+        n = sum(s.numel() for s in ctx.shapes)
+        flat = model.flat_grads[ctx.first:ctx.first + n].clone()
+        outs, off = [], 0
+        for i, shape in enumerate(ctx.shapes):
+            k = shape.numel()
+            outs.append(flat[off:off + k].view(shape) if ctx.needs_input_grad[4 + i] else None)
+            off += k
+        return (df, None, None, None, *outs)
+
+
 class MultiTaskNet(nn.Module):
     def __init__(self, num_joints, num_classes, image_size, compute_dtype=None, gelan_type="small", gelan_stages=3):
         super().__init__()
@@ -131,6 +167,7 @@ class MultiTaskNet(nn.Module):
         self.decoder = ViT(num_classes=num_classes, num_joints=num_joints,
                            feature_size=[image_size[0] // stride, image_size[1] // stride],
                            dim=256, depth=4, heads=8, head_dim=32, mlp_dim=256)   # multitasknet.py:14-22
+        object.__setattr__(self.decoder, "_owner", self)
         self.num_joints, self.num_classes = int(num_joints), int(num_classes)
         self.image_size = (int(image_size[0]), int(image_size[1]))
         if compute_dtype is None:
@@ -244,6 +281,32 @@ class MultiTaskNet(nn.Module):
             eng.fold_batchnorm()
         feats = eng.backbone_forward(x, training=self.training)
         return eng.features_plain(feats).float().permute(0, 3, 1, 2).contiguous()
+
+    def decoder_forward(self, feats):
+        """``self.decoder(feats)``: projected features float32 [B,256,h,w] -> (cls_out, hmap_out, attnmap) like the reference's
+        ViT.forward; differentiable in training mode (towards the features and the decoder's parameters)."""
+        fs = self.decoder.feature_size
+        if feats.dim() != 4 or feats.shape[1] != 256 or list(feats.shape[2:]) != list(fs):
+            raise ValueError(f"expected [B,256,{fs[0]},{fs[1]}], got {tuple(feats.shape)}")
+        feats = feats.to(torch.float32)
+        eng = self.engine(feats.shape[0])
+        if torch.is_grad_enabled() and self.training:
+            first, found = 0, False
+            for n, p in self.named_parameters():
+                if n.startswith("decoder."):
+                    found = True
+                    break
+                first += p.numel()
+            assert found
+            return _DecoderFunction.apply(feats, self, eng, first, *self.decoder.parameters())
+        eng.check_current()
+        if self.training:
+            eng.pack_weights()
+        else:
+            eng.fold_batchnorm()
+        eng.set_plain(eng.u_proj.raw, feats.permute(0, 2, 3, 1).contiguous())
+        logits, hm, attn = eng.vit_forward(True)
+        return logits.clone(), hm.clone(), (attn if self.share_attnmap else attn.clone())
 
     def forward(self, x):
         """x float32 [B,3,H,W] -> (cls_out [B,classes], hmap_out [B,joints,H/4,W/4], attnmap [B,8,N,N])."""

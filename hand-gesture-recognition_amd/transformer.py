@@ -83,4 +83,10 @@ class ViT(nn.Module):
         self.feature_size = list(feature_size)
 
     def forward(self, x):
-        raise RuntimeError("ViT runs inside the fused plan (engine.py)")
+        """transformer.py:129-152 on projected features [B, dim, h, w].  Runs in the plan of the MultiTaskNet that owns this
+        module (``model.decoder(feats)``); the reference adds the positional embedding INTO its argument (``x += pe`` on a view
+        of it, :135) -- here the argument is left as it was."""
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            raise RuntimeError("a ViT constructed on its own has no execution plan: use it as MultiTaskNet(...).decoder")
+        return owner.decoder_forward(x)

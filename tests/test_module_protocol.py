@@ -329,3 +329,40 @@ def test_standalone_gelannet_has_no_plan():
                                          (torch.bfloat16, 1e-1, 0.15)])     # (bf16: 5e-2 at config 5, B = 512; three 64x64 images are noisier)
 def test_encoder_on_its_own_gpu(dtype, tf, tg):
     _encoder_case(Backend("hip"), dtype, tf, tg, size=64, B=3)
+
+
+def _decoder_case(be, dtype, tol_f, tol_g, size=32, B=2):
+    """model.decoder(feats) on its own (transformer.py:129-152) against the oracle's ViT: outputs, the decoder's parameter
+    gradients and the gradient of the features."""
+    sd = O.synthetic_state_dict(21, 19, seed=13)
+    _, label, target, tw = O.synthetic_batch(B, size, seed=43)
+    h = size // 16
+    feats = 0.5 * torch.randn(B, 256, h, h, generator=torch.Generator().manual_seed(5))
+    sdo = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items() if k.startswith("decoder")}
+    fo = feats.clone().requires_grad_(True)
+    c_o, h_o, a_o = O.vit(fo, sdo)
+    O.total_loss(c_o, h_o, label, target, tw)[0].backward()
+    m = MultiTaskNet(21, 19, [size, size], compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m.to(be.device).train()
+    f = feats.clone().to(be.device).requires_grad_(True)
+    keep = f.detach().clone()
+    c, hm, a = m.decoder(f)
+    assert torch.equal(f.detach(), keep)                    # (the reference adds the positional embedding into its argument)
+    for got, want in ((c, c_o), (hm, h_o), (a, a_o)):
+        assert rel_err(got, want.detach()) < tol_f
+    O.total_loss(c, hm, label.to(be.device), target.to(be.device), tw.to(be.device))[0].backward()
+    worst = max(rel_err(p.grad, sdo["decoder." + k].grad) for k, p in m.decoder.named_parameters())
+    assert worst < tol_g, worst
+    assert rel_err(f.grad, fo.grad) < tol_g
+    assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("decoder."))
+
+
+def test_decoder_on_its_own_emu():
+    _decoder_case(Backend("emu"), torch.float32, 1e-3, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tf,tg", [(torch.float32, 1e-3, 1e-3), ("bf16x3", 1e-3, 2.5e-3), (torch.bfloat16, 3e-2, 0.15)])
+def test_decoder_on_its_own_gpu(dtype, tf, tg):
+    _decoder_case(Backend("hip"), dtype, tf, tg, size=64, B=3)
