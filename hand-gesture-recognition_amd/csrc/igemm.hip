@@ -79,8 +79,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_block) {
 //  holds it to 128 / 168)
 template <class T, int BM, int BN, int NT> struct IgemmOcc {
     static constexpr bool big = BM * BN >= 128 * 128;
-    static constexpr int lo = sizeof(T) == 4 ? (big ? (NT == 512 ? 4 : 1) : 3) : 1;
-    static constexpr int hi = big ? (sizeof(T) == 4 && NT == 512 ? 4 : 2) : 3;
+    static constexpr bool img = BM == 144;               // image tile: one workgroup per CU, all the registers it wants
+    static constexpr int lo = img ? 1 : (sizeof(T) == 4 ? (big ? (NT == 512 ? 4 : 1) : 3) : 1);
+    static constexpr int hi = img ? 2 : (big ? (sizeof(T) == 4 && NT == 512 ? 4 : 2) : 3);
 };
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
 __global__ __launch_bounds__(WGM* WGN * 64) MTN_WAVES_PER_SIMD((IgemmOcc<T, BM, BN, WGM * WGN * 64>::lo), (IgemmOcc<T, BM, BN, WGM * WGN * 64>::hi))
@@ -465,15 +466,19 @@ void igemm_kernel(IgemmArgs p) {
         // compiler counts vmcnt for register loads), and the K loop has NO barrier and no LDS writes -- the
         // waves of the workgroup drift apart and overlap each other's load and MFMA phases, which a workgroup
         // that meets at a barrier every K step cannot.
+        // (split storage at Cin = 256 is eight 32-channel blocks = 174 KB of window: the channels come in two passes of four
+        //  blocks -- the activations still cross L2 -> LDS once per tile, the accumulators carry over)
         constexpr int D = 3, KS = BK / KI;
-        dma_window(0);
-        __syncthreads();
         const int steps = 9 * CS;                          // CS in {1, 2, 4}: a multiple of D... 9, 18, 36
         const int cs_shift = CS == 4 ? 2 : (CS == 2 ? 1 : 0);
+        const int passes = p.Cin / (CS * BK);
         typename Mma<T>::Frag wq[D][KS][FN];
+        int pass = 0;
         auto load_w = [&](int kk, int slot) {
             const int tap = kk >> cs_shift, cs = kk - (tap << cs_shift);
-            const T* w = gW + (long)(n0 + wn * WN + frow) * p.K + tap * p.Cin + cs * BK + fk;
+            // (lane group g: the 16-byte slot g of the K step -- 8 bf16 channels, or the hi half of 8 split-storage channels,
+            //  whose lo half Mma<f32x3_t>::load finds 64 bytes on)
+            const T* w = gW + (long)(n0 + wn * WN + frow) * p.K + tap * p.Cin + (pass * CS + cs) * BK + fg * VEC;
             MTN_UNROLL for (int ks = 0; ks < KS; ++ks)
                 MTN_UNROLL for (int j = 0; j < FN; ++j) wq[slot][ks][j] = Mma<T>::load(w + (long)j * 16 * p.K + ks * KI);
         };
@@ -491,11 +496,16 @@ void igemm_kernel(IgemmArgs p) {
             mma_step([&](int ks, int i) { return RowFrag<T>::load(sWin + aoff[i], ks, fg, asw[i]); },
                      [&](int ks, int j) { return wq[slot][ks][j]; });
         };
-        MTN_UNROLL for (int d = 0; d + 1 < D; ++d) load_w(d, d);
-        for (int kk = 0; kk < steps; kk += D) {
-            MTN_UNROLL for (int d = 0; d < D; ++d) {
-                if (kk + d + D - 1 < steps) load_w(kk + d + D - 1, (d + D - 1) % D);
-                compute_img(kk + d, d);
+        for (; pass < passes; ++pass) {
+            if (pass) __syncthreads();                     // every wave is done with the previous pass's window
+            dma_window(pass);
+            __syncthreads();
+            MTN_UNROLL for (int d = 0; d + 1 < D; ++d) load_w(d, d);
+            for (int kk = 0; kk < steps; kk += D) {
+                MTN_UNROLL for (int d = 0; d < D; ++d) {
+                    if (kk + d + D - 1 < steps) load_w(kk + d + D - 1, (d + D - 1) % D);
+                    compute_img(kk + d, d);
+                }
             }
         }
         __syncthreads();                                   // every wave is done with the window: the C tile takes its place
@@ -826,13 +836,22 @@ static int g_image_tiles = 1;      // debug key 16: 0 = off, 1 = on, 3 = on and 
 constexpr int IMG_BM = 144, IMG_BN = 256;
 // (Measured and dropped: 288 x 128 with waves 2 x 4 for the 24 x 24 stage-2 maps, +10 % slower than the 128 x 128
 //  double buffer; 256 x 64 with waves 4 x 2 for stage 1, +25 % slower than the 53 KB window mode -- DESIGN.md 7c.)
-static bool igemm_image_tile_ok(const IgemmArgs& p, int esz) {
-    if (!g_image_tiles || (g_igemm_stages != 5 && g_igemm_stages < 7) || esz != 2 || !igemm_window_shape(p) || p.N % IMG_BN) return false;
-    const int bk = ROW_BYTES / esz, cs = p.Cin / bk;
-    if ((cs != 1 && cs != 2 && cs != 4) || p.Cin % bk) return false;
-    if (igemm_window_bytes(p, IMG_BM, 0, cs) > 158 * 1024) return false;
+// channel blocks resident per pass (0: the image tile does not apply).  bf16: all of Cin in one pass; split storage (esz 4):
+// the 256-channel layers take two passes of four 32-channel blocks (round 4)
+static int igemm_image_tile_cs(const IgemmArgs& p, int esz) {
+    if (!g_image_tiles || (g_igemm_stages != 5 && g_igemm_stages < 7) || !igemm_window_shape(p) || p.N % IMG_BN) return 0;
+    const int bk = ROW_BYTES / esz, blocks = p.Cin / bk;
+    if (p.Cin % bk) return 0;
+    int cs = blocks;
+    if (esz == 4 && blocks == 8) cs = 4;
+    if (cs != 1 && cs != 2 && cs != 4) return 0;
+    if (igemm_window_bytes(p, IMG_BM, 0, cs) > 158 * 1024) return 0;
     const long tiles = (long)mtn_cdiv(p.M, IMG_BM) * (p.N / IMG_BN);
-    return tiles >= 192 || (g_image_tiles & 2);     // one workgroup per CU: fewer tiles leave CUs idle
+    return (tiles >= 192 || (g_image_tiles & 2)) ? cs : 0;     // one workgroup per CU: fewer tiles leave CUs idle
+}
+static bool igemm_image_tile_ok(const IgemmArgs& p, int dtype) {
+    if (dtype != MTN_BF16 && dtype != MTN_F32X3) return false;
+    return igemm_image_tile_cs(p, dtype == MTN_BF16 ? 2 : 4) != 0;
 }
 
 template <class T, int BM, int BN, int WGM, int WGN, int STAGES, int MODE = 0>
@@ -846,7 +865,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
     int win_cs = 0;
     if (STAGES == 5 || STAGES == 6) {
-        win_cs = STAGES == 6 ? p.Cin / (ROW_BYTES / (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T), BM, BN);
+        win_cs = STAGES == 6 ? igemm_image_tile_cs(p, (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T), BM, BN);
         const size_t win = igemm_window_bytes(p, BM, STAGES == 6 ? 0 : BN, win_cs);
         const size_t rest = lds_c > lds_r ? lds_c : lds_r;
         lds = win > rest ? win : rest;
@@ -927,8 +946,8 @@ static int igemm_config(int M, int N, int K) {
 
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
-    if constexpr (sizeof(T) == 2) {
-        if (igemm_image_tile_ok(p, 2)) return launch_igemm<T, IMG_BM, IMG_BN, 1, 8, 6, 2>(p, stream);
+    if constexpr (sizeof(T) == 2 || std::is_same<T, f32x3_t>::value) {
+        if (igemm_image_tile_ok(p, sizeof(T) == 2 ? MTN_BF16 : MTN_F32X3)) return launch_igemm<T, IMG_BM, IMG_BN, 1, 8, 6, 2>(p, stream);
     }
     const int cfg = igemm_config(p.M, p.N, p.K);
     // 128x128 runs with 8 waves (4x2, 32x64 per wave) in the default pipelines: an LDS-DMA
@@ -997,7 +1016,7 @@ int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_tiles_m(p);
     if (mtn_pw_ok(p, dtype)) return mtn_pw_rows(p);
     if (mtn_win3_ok(p, dtype)) return mtn_win3_rows(p);
-    if (igemm_image_tile_ok(p, dtype == MTN_BF16 ? 2 : 4)) return mtn_cdiv(p.M, IMG_BM);
+    if (igemm_image_tile_ok(p, dtype)) return mtn_cdiv(p.M, IMG_BM);
     if (dtype == MTN_BF16 && ((g_igemm_stages == 7 && g_igemm_tile == 4) || (g_igemm_stages == 5 && g_igemm_tile >= 5)) && igemm_config(p.M, p.N, p.K) == 0)
         return mtn_cdiv(p.M, 256);
     return mtn_igemm_tiles_m(p.M, p.N, p.K);

@@ -126,6 +126,46 @@ def test_conv_image_tiles(be, image_tiles, cfg):
         assert rel_err(Fl(dx), dref) < tol(dtype)
 
 
+@pytest.mark.x3
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout   (split storage: 32-channel blocks; Cin = 256 = eight blocks runs as two passes of four)
+    (2, 12, 12, 64, 256),        # two resident blocks, one pass
+    (1, 13, 12, 128, 256),       # four blocks, one pass, a ragged second row tile
+    (2, 12, 12, 256, 256),       # eight blocks: two passes over the window
+    (1, 5, 7, 256, 512),         # two passes, one partial tile, two column tiles
+])
+def test_conv_image_tiles_split_storage(be, image_tiles, cfg):
+    """igemm_kernel<f32x3_t, 144, 256, 1, 8, window>: forward with statistics and data gradient with a residual, against torch"""
+    dtype = torch.float32
+    B, H, W, Cin, Cout = cfg
+    d = be.device
+    x = _rand((B, H, W, Cin), dtype, 71)
+    w = _rand((Cout, Cin, 3, 3), torch.float32, 72) / (Cin * 9) ** 0.5
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, None, 1, 1).permute(0, 2, 3, 1)
+    M = B * H * W
+    tiles = ops.conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, 3, 1)
+    assert tiles == (M + 143) // 144
+    y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=d)
+    stats = torch.full((tiles, 2, Cout), float("nan"), device=d)
+    ops.conv_fwd(A(x).to(d), pack_krsc(w, dtype).to(d), y, stats, 3, 1)
+    be.sync()
+    assert rel_err(Fl(y), ref) < 5e-5
+    yf = Fl(y).reshape(M, Cout)
+    assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3 and rel_err(stats.cpu().sum(0)[1], (yf * yf).sum(0)) < 1e-3
+    if Cout == 256:
+        w2 = _rand((Cin, Cout, 3, 3), torch.float32, 73) / (Cin * 9) ** 0.5
+        xz = torch.zeros((B, Cout, H, W), requires_grad=True)
+        yr = F.conv2d(xz, w2, None, 1, 1)
+        dy = _rand((B, H, W, Cin), dtype, 74)
+        res = _rand((B, H, W, Cout), dtype, 75)
+        yr.backward(dy.permute(0, 3, 1, 2))
+        dref = xz.grad.permute(0, 2, 3, 1) + res
+        dx = A(res).clone().to(d)
+        ops.conv_dgrad(A(dy).to(d), pack_crsk(w2, dtype).to(d), dx, dx, 3, 1)
+        be.sync()
+        assert rel_err(Fl(dx), dref) < 5e-5
+
+
 def test_conv_fwd_refuses_a_stats_slab_sized_for_another_tile(be):
     """A debug key that changes the tile after the plan sized its slab must fail the launch, not
     write a different number of statistics rows than bn_finalize will read."""
