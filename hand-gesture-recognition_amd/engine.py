@@ -58,6 +58,9 @@ class Engine:
         # optional callback(tag) fired inside backward() as soon as a contiguous group of parameter
         # gradients is final: "head" (projection + decoder), ("stage", i), "stem" -- in that order
         self.on_grads_ready = None
+        # bumped by every pass that overwrites the saved activations (backbone_forward / vit_forward): an autograd node of an
+        # older pass compares it with the value it saw and refuses to run backward on another pass's activations
+        self.serial = [0, 0]            # [backbone buffers, ViT buffers]
         # data gradients pre-reduce the BatchNorm backward of the unit they feed (MTN_FUSE_BN_BWD=0: two-pass backward)
         self.fuse_bn_bwd = os.environ.get("MTN_FUSE_BN_BWD", "1") != "0"
         self.fuse_gelu_bwd = os.environ.get("MTN_FUSE_GELU_BWD", "1") != "0"     # (0: three launches per FeedForward)
@@ -365,6 +368,7 @@ class Engine:
         fold_batchnorm() before an inference pass (forward() does either)."""
         u1, bn1 = self.u_conv1, self.u_conv1.mod.bn
         self.x_in = x
+        self.serial[0] += 1
         if training:
             self.o.conv1_stats(x, u1.wf, u1.stats)
             self.o.bn_finalize(u1.stats, u1.tiles, u1.M, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
@@ -411,6 +415,7 @@ class Engine:
         """ViT.forward (model/transformer.py:129-152) on the projected features in ``self.feat`` ([B*P, 256], the plan's
         storage): -> (logits, heatmaps, attnmap).  The packed weights must be current (pack_weights / fold_batchnorm)."""
         dec = self.model.decoder
+        self.serial[1] += 1
         self.o.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                    # transformer.py:132-139
         B, N, D, Hh = self.B, self.N, self.dim, self.heads
         Mt = B * N

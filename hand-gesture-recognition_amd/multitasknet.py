@@ -10,6 +10,8 @@ Deviations from the reference module, all deliberate:
   * ``attnmap`` is returned non-differentiable (the reference only visualises it, train.py:148-174); like the other two
     outputs it is a fresh tensor per call (a 172 MB copy at B = 256 / 145 tokens: ``share_attnmap = True`` hands out the
     plan's own buffer instead, which the next forward overwrites -- ``TrainStep`` never copies);
+  * one execution plan holds ONE pass's saved activations: ``o1 = m(x1); o2 = m(x2); loss(o1).backward()`` raises (the
+    reference's autograd graph would keep both passes alive); forward -> backward -> forward -> backward is the supported order;
   * (since round 4 the module is an ordinary autograd citizen otherwise: the image gets its gradient when it requires one -- a
     separate stem kernel, not part of the training step --, parameter gradients arrive through autograd's own accumulation
     nodes: hooks, ``requires_grad_(False)``, ``torch.autograd.grad`` and a ``DistributedDataParallel`` wrapper work; a
@@ -50,6 +52,18 @@ def resolve_compute_dtype(compute_dtype):
     raise ValueError(f"compute_dtype must be torch.bfloat16, torch.float32 or 'bf16x3', got {compute_dtype!r}")
 
 
+def _check_serial(ctx, eng, parts=(0, 1)):
+    """The saved activations of a node live in the plan's buffers (one set per batch size), not in the node: a later forward
+    through the same plan -- a second micro-batch, a GAN-style double forward, ``encoder(x)`` / ``decoder(f)`` after a full
+    forward -- overwrites them.  The reference's autograd graph would keep both; here the older node refuses to run instead
+    of returning gradients computed from the newer pass's activations."""
+    if any(ctx.serial[i] != eng.serial[i] for i in parts):        # (0: the backbone's buffers, 1: the ViT's)
+        raise RuntimeError("backward through a forward pass whose saved activations were overwritten: another forward "
+                           f"ran on this execution plan since (pass {list(ctx.serial)}, plan now at {eng.serial}).  Call backward "
+                           "before the next forward of the same batch size (one plan holds one pass's activations), or "
+                           "use a second model replica for interleaved passes")
+
+
 class _PlanFunction(torch.autograd.Function):
     """Connects Engine.forward/backward to autograd: ONE node for the whole network whose inputs are the image and every
     parameter, so that autograd itself delivers the gradients -- its per-parameter accumulation nodes set / add ``p.grad``
@@ -61,7 +75,7 @@ class _PlanFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, engine, *params):
         logits, hm, attn = engine.forward(x, training=model.training)
-        ctx.model, ctx.engine = model, engine
+        ctx.model, ctx.engine, ctx.serial = model, engine, tuple(engine.serial)
         ctx.shapes = [p.shape for p in params]
         attn = attn if model.share_attnmap else attn.clone()
         ctx.mark_non_differentiable(attn)
@@ -70,6 +84,7 @@ class _PlanFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, dhm, _dattn):
         eng, model = ctx.engine, ctx.model
+        _check_serial(ctx, eng)
         dlogits = torch.zeros_like(eng.logits) if dlogits is None else dlogits.contiguous()
         dhm = torch.zeros_like(eng.hm) if dhm is None else dhm.contiguous()
         dx = torch.empty_like(eng.x_in) if ctx.needs_input_grad[0] else None
@@ -94,13 +109,14 @@ class _BackboneFunction(torch.autograd.Function):
         engine.check_current()
         engine.pack_weights()
         feats = engine.backbone_forward(x, training=True)
-        ctx.model, ctx.engine, ctx.shapes = model, engine, [p.shape for p in params]
+        ctx.model, ctx.engine, ctx.shapes, ctx.serial = model, engine, [p.shape for p in params], tuple(engine.serial)
         return engine.features_plain(feats).float().permute(0, 3, 1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, g):
         eng, model = ctx.engine, ctx.model
         eng.check_current()
+        _check_serial(ctx, eng, parts=(0,))
         gbuf = eng.stages[-1]["g_out"]
         eng.set_plain(gbuf, g.permute(0, 2, 3, 1).contiguous().float())
         dx = torch.empty_like(eng.x_in) if ctx.needs_input_grad[0] else None
@@ -127,6 +143,7 @@ class _DecoderFunction(torch.autograd.Function):
         engine.set_plain(engine.u_proj.raw, feats.permute(0, 2, 3, 1).contiguous())
         logits, hm, attn = engine.vit_forward(True)
         ctx.model, ctx.engine, ctx.first, ctx.shapes = model, engine, first, [p.shape for p in params]
+        ctx.serial = tuple(engine.serial)
         attn = attn if model.share_attnmap else attn.clone()
         ctx.mark_non_differentiable(attn)
         return logits.clone(), hm.clone(), attn
@@ -135,6 +152,7 @@ class _DecoderFunction(torch.autograd.Function):
     def backward(ctx, dlogits, dhm, _dattn):
         eng, model = ctx.engine, ctx.model
         eng.check_current()
+        _check_serial(ctx, eng, parts=(1,))
         dlogits = torch.zeros_like(eng.logits) if dlogits is None else dlogits.contiguous()
         dhm = torch.zeros_like(eng.hm) if dhm is None else dhm.contiguous()
         eng.vit_backward(dlogits, dhm)

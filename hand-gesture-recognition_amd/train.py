@@ -157,6 +157,13 @@ class TrainStep:
     def _update(self):
         mdl = self.model
         ops.adamw_step(mdl.flat_params, mdl.flat_grads, self.m, self.v, self.state)
+        self._weights_moved()
+
+    def _weights_moved(self):
+        """The fused AdamW writes the flat parameter buffer through raw pointers (no version bump), and a graph replay packs
+        and updates without running any Python: the plan's record of what its packed weight copy holds is void after
+        either -- an eval forward with ``refold=False`` must fold again rather than serve this step's unfolded pack."""
+        self.eng._packed = None
 
     @staticmethod
     def _bucket_ranges(model):
@@ -254,6 +261,7 @@ class TrainStep:
         if self.world > 1:
             self._sync_grads()
             self._graph[1].replay()
+        self._weights_moved()
         return self.eng.losses
 
     # -- optimizer state for checkpoints ------------------------------------------------------------
@@ -370,7 +378,7 @@ def test(model, eng, batches, num_classes, out_dir=None, names=None):
             meter.update(eng.logits, label)
     model.train(was_training)
     f1 = float(meter.f1())
-    cm = meter.cm.t().cpu().numpy()                        # the meter counts [true][pred]
+    cm = meter.cm.cpu().numpy()                            # the meter counts cm[pred][label] (include/mtn.h: mtn_cls_confusion)
     print("Test F1 Score: {:.4f}".format(f1), flush=True)                                    # train.py:178
     if out_dir is not None:
         import numpy as np

@@ -51,6 +51,39 @@ def test_inference_session_eager_emu(dtype, tol):
     _case(Backend("emu"), dtype, False, tol)
 
 
+def _train_step_between_eval_forwards(be, use_graph):
+    """eval forward, then a training step on the SAME plan (it re-packs unfolded weights and moves them
+    through raw pointers: no version bump; under ``use_graph`` without running any Python), then an eval forward that
+    promises ``refold=False``: the plan must notice and fold again instead of serving unfolded weights with folded biases."""
+    from hand_gesture_recognition_amd.train import TrainStep
+    model, _ = _model(be, torch.float32)
+    batch = [t.to(be.device) for t in O.synthetic_batch(2, 32, seed=31)]
+    eng = model.engine(2)
+    step = TrainStep(model, 2, lr=1e-2, use_graph=use_graph)
+    for _ in range(2):                                     # (graph: capture on the first call, a pure replay on the second)
+        model.eval()
+        with torch.no_grad():
+            eng.forward(batch[0], training=False)
+        model.train()
+        step(*batch)
+        model.eval()
+        with torch.no_grad():
+            got = [t.clone() for t in eng.forward(batch[0], training=False, refold=False)]
+            ref = [t.clone() for t in eng.forward(batch[0], training=False, refold=True)]
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+
+
+def test_eval_after_train_step_refolds_emu():
+    _train_step_between_eval_forwards(Backend("emu"), False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_eval_after_train_step_refolds_gpu(use_graph):
+    _train_step_between_eval_forwards(Backend("hip"), use_graph)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), ("bf16x3", 1e-3), (torch.bfloat16, 3e-2)], ids=["f32", "x3", "bf16"])

@@ -187,6 +187,45 @@ def test_outputs_are_fresh_tensors_per_call():
     assert first[2].data_ptr() == m.engine(2).attn.data_ptr()
 
 
+def test_backward_of_an_overwritten_pass_raises():
+    """ADVICE round 4: a node's saved activations live in the plan, not in the node.  ``o1 = m(x1); o2 = m(x2);
+    loss(o1).backward()`` used to return gradients computed from x2's activations (1.2 off in relative norm) without an
+    error; it now raises, the newer pass still runs, and the chained encoder -> proj -> decoder graph (two nodes that
+    share one plan but not their buffers) is not a false positive."""
+    Backend("emu")
+    sd = O.synthetic_state_dict(21, 19, seed=8)
+    b0, b1 = O.synthetic_batch(2, 32, seed=21), O.synthetic_batch(2, 32, seed=22)
+    m = MultiTaskNet(21, 19, [32, 32], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+
+    def loss_of(out, b):
+        return O.total_loss(out[0], out[1], b[1], b[2], b[3])[0]
+
+    o1 = m(b0[0])
+    o2 = m(b1[0])
+    with pytest.raises(RuntimeError, match="saved activations were overwritten"):
+        loss_of(o1, b0).backward()
+    loss_of(o2, b1).backward()                            # the pass whose activations the plan holds is fine
+    g2 = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    m.zero_grad(set_to_none=True)
+    loss_of(m(b1[0]), b1).backward()
+    assert rel_err(torch.cat([p.grad.flatten() for p in m.parameters()]), g2) < 1e-6
+    # a decoder-only forward after a full forward overwrites the ViT buffers of that pass
+    m.zero_grad(set_to_none=True)
+    o1 = m(b0[0])
+    with torch.no_grad():
+        f = m.proj(m.encoder(b0[0]))
+    m.decoder(f.detach())
+    with pytest.raises(RuntimeError, match="saved activations were overwritten"):
+        loss_of(o1, b0).backward()
+    # chained sub-modules: the decoder's forward does not invalidate the encoder's node
+    m.zero_grad(set_to_none=True)
+    c, h, _ = m.decoder(m.proj(m.encoder(b0[0])))
+    O.total_loss(c, h, b0[1], b0[2], b0[3])[0].backward()
+    assert all(p.grad is not None for p in m.parameters())
+
+
 def _image_grad_case(be, dtype, tol, size=32, B=2):
     sd = O.synthetic_state_dict(21, 19, seed=9)
     img, label, target, tw = O.synthetic_batch(B, size, seed=23)
