@@ -7,8 +7,10 @@ numpy restatement of the reference's host-side evaluation code (SURVEY.md sectio
   generate_target    libs/load.py:148-206
 Pinning: get_max_preds / pose_accuracy are checked against the reference's own functions (they
 import with numpy only) by oracle/gen_golden_metrics.py -> tests/golden/metrics.npz.
-generate_target lives in libs/load.py, which needs cv2 / lightning / torchvision (absent here), so
-it is restated from the source text only: PARITY UNPINNED for target rendering.
+generate_target lives in libs/load.py, whose module imports cv2 / lightning / torchvision (absent here); the method
+itself needs only numpy: oracle/gen_golden_targets.py compiles that one function node from the reference's file (build
+container only), checks this restatement returns identical arrays on 15 edge-case sets and writes the reference's
+inputs / outputs to tests/golden/targets.npz (round 5: pinned).
 Only tests/ may import this file.
 """
 import numpy as np

@@ -88,6 +88,30 @@ def test_classification_meter_guards_labels(be):
     assert int(meter.cm.sum()) == 3
 
 
+def test_render_targets_match_the_reference_vectors(be, golden_dir):
+    """SURVEY 8f row 2 pinned: tests/golden/targets.npz holds inputs and outputs of the REFERENCE's own
+    ``HagridDataset.generate_target`` (libs/load.py:148-206; oracle/gen_golden_targets.py compiled that method from the
+    reference's file in the build container): borders and corners, both sides of the in / out test, invisible joints,
+    v > 0.5, round-half-up of the centre, negative coordinates, non-square maps, sigma 1 / 2 / 3, the 192 x 192 default."""
+    g = np.load(os.path.join(golden_dir, "targets.npz"))
+    assert len(g["names"]) >= 15
+    for name in g["names"]:
+        joints, vis = g[f"{name}.joints"], g[f"{name}.vis"]
+        iw, ih = (int(v) for v in g[f"{name}.image_size"])             # the reference's image_size[0] goes with x
+        sigma = int(g[f"{name}.sigma"])
+        rt, rw = g[f"{name}.target"], g[f"{name}.weight"]
+        # the restatement the other CPU tests use is the same function
+        ot, ow = M.generate_target(joints.astype(np.float64), vis.astype(np.float64)[:, None], (iw, ih), (iw // 4, ih // 4), sigma)
+        assert np.array_equal(ot, rt) and np.array_equal(ow, rw), name
+        tgt, w = metrics.render_targets(torch.from_numpy(joints)[None].to(be.device), torch.from_numpy(vis)[None].to(be.device),
+                                        (ih, iw), sigma)
+        be.sync()
+        tgt, w = tgt[0].cpu().numpy(), w[0].cpu().numpy()
+        assert tgt.shape == rt.shape and np.array_equal(w, rw), name
+        assert np.array_equal(tgt != 0, rt != 0), name                 # the same pixels are drawn
+        assert np.allclose(tgt, rt, atol=1e-6, rtol=0), (name, float(np.abs(tgt - rt).max()))
+
+
 def test_render_targets_and_normalize(be):
     rng = np.random.default_rng(5)
     B, J, S = 3, 21, 64
