@@ -65,15 +65,35 @@ def parse():
 _DT = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
 
 
-def igemm_roofline(step, batch, mode="bf16"):
-    """Time every launch of the dominant kernel (the `igemm_kernel` template: every convolution
-    forward / data gradient and every ViT linear) inside one real training step.
+STEP_GB_ONE_READ_ONE_WRITE = 14.1   # 55 MB per image x 256 (each tensor read once, written once)
 
-    achieved = algorithmic FLOPs of those launches / their summed durations (HIP events on the
-    launch stream around each call; each call is exactly one igemm_kernel launch).
-    """
+
+def _pmc_file(mode):
+    """newest committed rocprofv3 PMC summary of this same command (FETCH_SIZE / WRITE_SIZE collected in separate passes and
+    corrected as MI355X_MICROARCH.md prescribes; tools/refresh_profiles.sh) -> (dict, 'profiles/<name>') or (None, None)"""
+    import re
+    tag = "" if mode == "bf16" else mode + "_"
+    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic_" + tag + r"v\d+\.json$", n)]   # (not the configs' files)
+    # newest collection: highest round, then highest version (r02_..._v3 > r02_..._v2 > r01_..._v10)
+    cands.sort(key=lambda n: [int(x) for x in re.findall(r"\d+", n)], reverse=True)
+    for name in cands:
+        return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
+    return None, None
+
+
+def igemm_roofline(step, batch, mode="bf16"):
+    """Time every conv forward / conv data gradient / ViT Linear launch inside one real training step (HIP events on the
+    launch stream around each call; each call is exactly one kernel launch) and report them BY THE KERNEL THAT SERVED THEM
+    (ops.conv_kernel_family = the library's own launch rules): the `igemm_kernel` template (the dominant kernel: the object
+    itself), `pw_kernel` and `dgrad2_kernel` as families of their own.
+
+    achieved = algorithmic FLOPs of the igemm_kernel launches / their summed durations; `traffic` = measured HBM bytes per
+    launch of the SAME population (the igemm_kernel rows of the committed PMC summary except the GELU'-fused instantiation,
+    whose calls are not bracketed here)."""
     from hand_gesture_recognition_amd import ops
     rec = []
+    dt = step.eng.dt
+    fcode = step.eng.f32_code
 
     def wrap(name, fn, geom):
         def inner(*a, **k):
@@ -90,20 +110,24 @@ def igemm_roofline(step, batch, mode="bf16"):
         return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
     def g_fwd(x, w, y, stats, k, s, stats_tiles=None, **kw):
-        Cin, Cout, M = x.shape[-1], y.shape[-1], y.numel() // y.shape[-1]
-        return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y), k
+        B, H, W, Cin = x.shape
+        Cout, M = y.shape[-1], y.numel() // y.shape[-1]
+        fam = ops.conv_kernel_family(dt, False, B, H, W, Cin, Cout, k, s, mode=fcode)
+        return 2.0 * M * Cout * k * k * Cin, nbytes(x, w, y), k, fam
 
     def g_dgrad(dy, wt, dx, res, k, s, bn=None, **kw):
         Cout, Cin, Mout = dy.shape[-1], dx.shape[-1], dy.numel() // dy.shape[-1]
+        B, H, W = dx.shape[0], dx.shape[1], dx.shape[2]
         # (a launch that also writes the BatchNorm-backward sums of the next unit reads that unit's raw output too)
         extra = (bn[0], bn[1]) if bn is not None else ()
-        # 3x3 stride-2 data gradients run dgrad2_kernel, not the igemm template: their own family below
-        return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res, *extra), (32 if (k == 3 and s == 2) else k)
+        fam = ops.conv_kernel_family(dt, True, B, H, W, Cin, Cout, k, s, has_res=res is not None, has_bn=bn is not None, mode=fcode)
+        return 2.0 * Mout * Cout * k * k * Cin, nbytes(dy, wt, dx, res, *extra), k, fam
 
     def g_lin(x, w, out, bias=None, act=0, aux_out=None, res=None, **kw):
         K, N = x.shape[-1], out.shape[-1]
         M = x.numel() // K
-        return 2.0 * M * N * K, nbytes(x, w, out, aux_out, res), 1
+        fam = ops.conv_kernel_family(dt, False, M, 1, 1, K, N, 1, 1, has_res=res is not None, mode=fcode)
+        return 2.0 * M * N * K, nbytes(x, w, out, aux_out, res), 1, fam
 
     saved = (ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd)
     ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = (wrap("conv_fwd", saved[0], g_fwd), wrap("conv_dgrad", saved[1], g_dgrad),
@@ -113,59 +137,58 @@ def igemm_roofline(step, batch, mode="bf16"):
         torch.cuda.synchronize()
     finally:
         ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = saved
-    all_times = [r[2].elapsed_time(r[3]) * 1e-3 for r in rec]
-    d2 = [(r, t) for r, t in zip(rec, all_times) if r[1][2] == 32]
-    keep = [(r, t) for r, t in zip(rec, all_times) if r[1][2] != 32]
-    rec, times = [r for r, _ in keep], [t for _, t in keep]
-    flops = sum(r[1][0] for r in rec)
-    abytes = sum(r[1][1] for r in rec)
-    secs = sum(times)
+    # (flops, algorithmic bytes, kernel size, seconds) per launch, grouped by the kernel source that served it
+    by = {}
+    for name, (fl, by_, k, famc), e0, e1 in rec:
+        by.setdefault(ops.KERNEL_FAMILIES[famc], []).append((fl, by_, k, e0.elapsed_time(e1) * 1e-3, famc))
+
+    def fam_obj(rows, bound, kernel=None):
+        f, b, t = sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[3] for r in rows)
+        o = {"bound": bound}
+        if kernel:
+            o["kernel"] = kernel
+        if bound == "mfma":
+            o.update({"achieved": round(f / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "gbs": round(b / t / 1e9, 1)})
+        else:
+            o.update({"achieved": round(b / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4),
+                      "tflops": round(f / t / 1e12, 1)})
+        o.update({"launches_per_step": len(rows), "share_of_step_ms": round(t * 1e3, 3)})
+        return o
+
+    ig = by.get("igemm_kernel", [])
+    flops, abytes, secs = sum(r[0] for r in ig), sum(r[1] for r in ig), sum(r[3] for r in ig)
     achieved = flops / secs / 1e12
-    # the template's two regimes, reported separately as well: 3x3 convolutions (forward and data gradient;
-    # MFMA-bound: 288..1152 flop/B) and 1x1 convolutions / Linears (HBM-bound: 64..256 flop/B)
-    fam = {}
-    for r, t in zip(rec, times):
-        k = "conv3x3" if r[1][2] == 3 else "pointwise"
-        f = fam.setdefault(k, [0.0, 0.0, 0.0, 0])
-        f[0] += r[1][0]; f[1] += r[1][1]; f[2] += t; f[3] += 1
-    families = {
-        "conv3x3": {"bound": "mfma", "achieved": round(fam["conv3x3"][0] / fam["conv3x3"][2] / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fam["conv3x3"][0] / fam["conv3x3"][2] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "launches_per_step": fam["conv3x3"][3], "share_of_step_ms": round(fam["conv3x3"][2] * 1e3, 3)},
-        "pointwise": {"bound": "hbm", "achieved": round(fam["pointwise"][1] / fam["pointwise"][2] / 1e9, 1), "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": round(fam["pointwise"][1] / fam["pointwise"][2] / 1e9 / HBM_PEAK_GBS, 4),
-                      "launches_per_step": fam["pointwise"][3], "share_of_step_ms": round(fam["pointwise"][2] * 1e3, 3)},
-    }
-    if d2:
-        f2, b2, t2 = sum(r[1][0] for r, _ in d2), sum(r[1][1] for r, _ in d2), sum(t for _, t in d2)
-        families["conv3x3_stride2_dgrad"] = {"kernel": "dgrad2_kernel", "bound": "hbm", "achieved": round(b2 / t2 / 1e9, 1),
-                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b2 / t2 / 1e9 / HBM_PEAK_GBS, 4),
-                                             "tflops": round(f2 / t2 / 1e12, 1), "launches_per_step": len(d2),
-                                             "share_of_step_ms": round(t2 * 1e3, 3)}
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    # (FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes),
-    # averaged over all instances of the template
-    traffic, src = None, None
-    import re
-    tag = "" if mode == "bf16" else mode + "_"
+    # the template's two regimes, reported separately as well: 3x3 convolutions (forward and data gradient; MFMA-bound:
+    # 288..1152 flop/B) and 1x1 convolutions / Linears (HBM-bound: 64..256 flop/B); then the kernels outside the template
+    families = {"conv3x3": fam_obj([r for r in ig if r[2] == 3], "mfma", "igemm_kernel (3x3 taps: streamed tiles, window, image tiles)"),
+                "pointwise": fam_obj([r for r in ig if r[2] == 1], "hbm", "igemm_kernel (1x1 taps: convolutions and Linears)")}
+    if by.get("pw_kernel"):
+        families["pointwise_persistent"] = fam_obj(by["pw_kernel"], "hbm", "pw_kernel")
+    if by.get("dgrad2_kernel"):
+        families["conv3x3_stride2_dgrad"] = fam_obj(by["dgrad2_kernel"], "hbm", "dgrad2_kernel")
+    # HBM bytes per launch of the same population from the committed PMC passes of this same command
+    traffic, src, whole = None, None, None
     tname = {"bf16": "bf16_t", "bf16x3": "f32x3_t", "fp32": "float"}[mode]
-    cands = [n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_hbm_traffic_" + tag + r"v\d+\.json$", n)]   # (not the configs' files)
-    # newest collection: highest round, then highest version (r02_..._v3 > r02_..._v2 > r01_..._v10)
-    cands.sort(key=lambda n: [int(x) for x in re.findall(r"\d+", n)], reverse=True)
-    for name in cands:
-        pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-        tot = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<" + tname))
-        n = sum(v["dispatches"] for k, v in pm.items() if k.startswith("igemm_kernel<" + tname))
+    pm, src = _pmc_file(mode)
+    if pm is not None:
+        rows = {k: v for k, v in pm.items() if k.startswith("igemm_kernel<" + tname) and not k.rstrip().endswith(", 4>")}
+        n = sum(v["dispatches"] for v in rows.values())
         if n:
-            traffic, src = round(tot / n), "profiles/" + name
-        break
-    out = {"bound": "mfma", "kernel": "igemm_kernel<" + tname + ",...> (all instances: conv fwd + conv dgrad + ViT linears, one launch per call; not counted: "
-                      "the 4 fc2 data gradients fused with GELU' / bias sums, whose call brackets three launches)",
+            traffic = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in rows.values()) / n)
+        steps_profiled = max([v["dispatches"] for k, v in pm.items() if k.startswith("adamw_kernel")] or [0])
+        if steps_profiled:
+            whole = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in pm.values()) / steps_profiled
+    out = {"bound": "mfma", "kernel": "igemm_kernel<" + tname + ",...> (all instances of the template that one call = one launch brackets: conv forward, "
+                      "conv data gradient, ViT Linears; pw_kernel and dgrad2_kernel launches are families of their own below; not "
+                      "counted: the 4 fc2 data gradients fused with GELU' / bias sums, whose call brackets three launches)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-            "launches_per_step": len(rec), "avg_launch_us": round(secs / len(rec) * 1e6, 1),
-            "flops_per_launch": round(flops / len(rec)), "algorithmic_bytes_per_launch": round(abytes / len(rec)),
-            "share_of_step_ms": round(secs * 1e3, 3), "families": families}
+            "launches_per_step": len(ig), "avg_launch_us": round(secs / len(ig) * 1e6, 1),
+            "flops_per_launch": round(flops / len(ig)), "algorithmic_bytes_per_launch": round(abytes / len(ig)),
+            "traffic_over_algorithmic": round(traffic / (abytes / len(ig)), 3) if traffic else None,
+            "share_of_step_ms": round(secs * 1e3, 3), "families": families,
+            "whole_step_hbm_bytes_measured": round(whole) if whole else None}
     if mode == "bf16x3":
         # `achieved` counts ALGORITHMIC flops (2 M N K); the split-bf16 product issues three bf16 MFMAs per one of them
         out["mfma_issue_frac"] = round(3 * achieved / MFMA_BF16_PEAK_TFLOPS, 4)
@@ -454,6 +477,12 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el), mine, losses
 
+    # proof of what the process group saw: a ones tensor summed over the group (RCCL for N > 1) = the number of ranks
+    ones = torch.ones(1, device=dev)
+    if world > 1:
+        dist.all_reduce(ones)
+    ranks_counted = int(ones.item())
+    assert ranks_counted == world, f"the all-reduce saw {ranks_counted} ranks, WORLD_SIZE={world}"
     for _ in range(a.warmup):
         step(*batch)
     elapsed, mine, losses = window()                   # THE timed region
@@ -473,6 +502,26 @@ def main():
         dist.all_reduce(rank_ms)
         dist.all_reduce(comm_ms)
     extra = [window()[0] / a.steps * 1e3 for _ in range(max(0, a.windows))]
+    # N > 1: the same step WITHOUT partners, in the same processes and through the same bucketed all-reduce path, on a
+    # one-rank group per rank -- the N = 1 figure this run's scaling can be checked against directly (the driver computes
+    # efficiency from its own N = 1 run; this one shares the box, the clocks and the process with the N-rank figure)
+    n1 = None
+    if world > 1:
+        groups = [dist.new_group([r]) for r in range(world)]          # (collective: every rank creates every group)
+        step1 = TrainStep(model, a.batch, lr=1e-3, process_group=groups[rank], overlap_comm="force")
+        for _ in range(min(a.warmup, 3)):
+            step1(*batch)
+        bracket()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step1(*batch)
+        bracket()
+        el1 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(el1, op=dist.ReduceOp.MAX)
+        n1 = {"ms_per_step_max_over_ranks": round(float(el1) / a.steps * 1e3, 3),
+              "images_per_sec_per_gpu": round(a.batch * a.steps / float(el1), 1),
+              "how": "TrainStep on a one-rank process group per rank (bucketed all-reduce launched, no partner), all ranks at once"}
+        del step1
 
     roof = None
     if not a.no_roofline:
@@ -491,6 +540,8 @@ def main():
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "hipgraph": bool(a.graph)},
             "algorithmic_tflops": round(ips * gflop / 1e3, 1) if gflop else None,
             "mfma_frac_whole_step": round(ips * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS / world, 4) if gflop else None,
+            # one-read-one-write byte model of SURVEY 8(d) (55 MB per image, bf16) against the HBM roof at this step time
+            "hbm_frac_whole_step_algorithmic": round(ips / world * 55e6 / 1e9 / HBM_PEAK_GBS, 4) if (a.size == 192 and a.dtype == "bf16") else None,
             "final_losses": [round(x, 6) for x in loss_val],
             "timing_windows": {"ms_per_step": [round(x, 3) for x in all_ms], "min": round(min(all_ms), 3),
                                "median": round(statistics.median(all_ms), 3),
@@ -498,13 +549,21 @@ def main():
                                "note": "window 0 is the timed region `value` is computed from"},
         }
         if world > 1:
-            out["ranks"] = {"rccl_ranks": world, "backend": dist.get_backend(), "ms_per_step_per_rank": [round(float(x), 3) for x in rank_ms],
+            out["ranks"] = {"rccl_ranks": ranks_counted, "rccl_ranks_how": "all-reduce (sum) of a ones tensor over the group", "backend": dist.get_backend(), "ms_per_step_per_rank": [round(float(x), 3) for x in rank_ms],
                             "comm_exposed_ms_per_rank": [round(float(x), 4) for x in comm_ms],
                             "comm_exposed_ms": round(float(comm_ms.max()), 4),
                             "gradient_bytes_all_reduced": int(model.n_params * 4), "buckets": len(step._buckets),
-                            "overlap_with_backward": bool(step.overlap)}
+                            "overlap_with_backward": bool(step.overlap), "n1_same_processes": n1}
         if roof is not None:
             out["roofline"] = roof
+            wb = roof.pop("whole_step_hbm_bytes_measured", None)
+            if wb and a.size == 192 and a.batch == 256:
+                # measured HBM bytes of one step (all kernels of the committed PMC summary) at THIS run's step time, and
+                # against the one-read-one-write model: > 1 = passes that re-read / re-write tensors (BatchNorm, split-K slabs)
+                out["hbm_whole_step"] = {"measured_gb_per_step": round(wb / 1e9, 2), "source": roof["traffic_source"],
+                                         "hbm_frac": round(wb / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "traffic_ratio": round(wb / 1e9 / (STEP_GB_ONE_READ_ONE_WRITE * (2 if a.dtype != "bf16" else 1)), 3),
+                                         "one_read_one_write_gb": STEP_GB_ONE_READ_ONE_WRITE * (2 if a.dtype != "bf16" else 1)}
     del step, model
     torch.cuda.empty_cache()
     if rank == 0 and world == 1:

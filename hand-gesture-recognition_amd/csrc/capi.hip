@@ -26,7 +26,7 @@ int mtn_check_launch(const char* what) {
 extern "C" {
 
 const char* mtn_last_error(void) { return g_err; }
-int mtn_abi_version(void) { return 5; }
+int mtn_abi_version(void) { return 6; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
@@ -186,16 +186,25 @@ size_t mtn_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int Cin, i
     return (size_t)p.splits * p.N * p.K * sizeof(float);
 }
 
-int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
-                   size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
-                   int stride, void* stream) {
+int mtn_conv_wgrad_phase(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                         size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                         int stride, int phase, void* stream) {
     MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_wgrad: ksize=%d", ksize);
     MTN_REQUIRE(stride == 1 || stride == 2, "conv_wgrad: stride=%d", stride);
+    MTN_REQUIRE(phase >= 1 && phase <= 3, "conv_wgrad: phase=%d", phase);
     WgradArgs p{};
     if (conv_wgrad_args(p, dtype, B, H, W, Cin, Cout, ksize, stride)) return MTN_ERR_BAD_ARG;
     MTN_REQUIRE(ws_bytes >= (size_t)p.splits * p.N * p.K * sizeof(float), "conv_wgrad: workspace too small");
+    MTN_REQUIRE(workspace && (phase == 1 || dw) && (phase == 2 || (x && dy)), "conv_wgrad: null operand for phase %d", phase);
     p.dY = dy; p.lddy = lddy; p.X = x; p.ldx = ldx; p.partial = (float*)workspace; p.dW = dw;
+    p.phase = phase;
     return mtn_wgrad_run(p, dtype, (hipStream_t)stream);
+}
+
+int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                   size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                   int stride, void* stream) {
+    return mtn_conv_wgrad_phase(x, ldx, dy, lddy, dw, workspace, ws_bytes, dtype, B, H, W, Cin, Cout, ksize, stride, 3, stream);
 }
 
 size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K) {
@@ -412,18 +421,38 @@ static bool debug_keys_allowed() {
     return ok;
 }
 
+int mtn_has_experiments(void) { return mtn_igemm_has_experiments() != 0; }
+
+// keys / values that select a measured-and-rejected variant exist in -DMTN_EXPERIMENTS builds only (the CPU executor library,
+// diagnostic GPU builds): the product library does not contain those kernels and says so.  (Keys 2 / 14 choose an older
+// generation of the pose-head kernels where a newer one applies: the older ones ship only as the fallback for the map
+// sizes the newer ones do not take.)
+int mtn_debug_key_is_experiment(int key, int value) {
+    return (key == 1 && value == 0) || (key == 3 && value != 5) || (key == 4 && value == 256) || (key == 5 && value == 0) ||
+           (key == 6 && value >= 4) || (key == 7 && value != 0 && value != 64) || (key == 19 && value != 0 && value != 8) ||
+           (key == 20 && value != 0) || (key == 8 && value == 5) || (key == 2 && value != 0) || (key == 14 && value == 0) ||
+           ((key == 26 || key == 27) && value != 0) || key == 23;
+}
+
+int mtn_conv_kernel_family(int dtype, int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int has_res,
+                           int has_bn) {
+    IgemmArgs p{};
+    if (dgrad ? conv_dgrad_args(p, "conv_kernel_family", B, H, W, Cin, Cout, ksize, stride)
+              : conv_fwd_args(p, "conv_kernel_family", B, H, W, Cin, Cout, ksize, stride))
+        return -1;
+    if (has_res) p.res = &p;            // (only their presence matters to the launch rules)
+    if (has_bn) p.bn_y = &p;
+    return mtn_igemm_family(p, dtype);
+}
+
 int mtn_debug_set(int key, int value) {
     if (!debug_keys_allowed()) {
         mtn_set_error("debug_set: diagnostic keys are disabled in this process (set MTN_ALLOW_DEBUG_KEYS=1 in the environment "
                       "before the first call); the product path has no mutable configuration");
         return MTN_ERR_UNSUPPORTED;
     }
-    // keys / values that select a measured-and-rejected variant exist in -DMTN_EXPERIMENTS builds only (the CPU executor library,
-    // diagnostic GPU builds): the product library does not contain those kernels and says so
     const bool ex = mtn_igemm_has_experiments() != 0;
-    const bool needs_ex = (key == 1 && value == 0) || (key == 3 && value != 5) || (key == 4 && value == 256) || (key == 5 && value == 0) ||
-                          (key == 6 && value >= 4) || (key == 7 && value != 0 && value != 64) || (key == 19 && value != 0 && value != 8) ||
-                          (key == 20 && value != 0) || (key == 8 && value == 5);
+    const bool needs_ex = mtn_debug_key_is_experiment(key, value) != 0;
     if (needs_ex && !ex) {
         mtn_set_error("debug_set: key %d = %d selects a measured-and-rejected kernel variant that this build does not contain "
                       "(built without -DMTN_EXPERIMENTS)", key, value);

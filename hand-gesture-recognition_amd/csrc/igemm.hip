@@ -1022,6 +1022,21 @@ int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     return mtn_igemm_tiles_m(p.M, p.N, p.K);
 }
 
+// the kernel mtn_igemm_run launches for these arguments (same rules, no launch): MTN_KERNEL_* of include/mtn.h
+int mtn_igemm_family(const IgemmArgs& p, int dtype) {
+    if (mtn_dgrad2_ok(p, dtype)) return MTN_KERNEL_DGRAD2;
+    if (mtn_pw_ok(p, dtype)) return MTN_KERNEL_PW;
+    if (mtn_win3_ok(p, dtype)) return MTN_KERNEL_WIN3;
+    if (igemm_image_tile_ok(p, dtype)) return MTN_KERNEL_IGEMM_IMAGE;
+    const int esz = dtype == MTN_BF16 ? 2 : 4;
+    if (g_igemm_stages == 5 && !p.pm && igemm_window_shape(p)) {
+        static const int bm[4] = {128, 64, 256, 128}, bn[4] = {128, 128, 64, 64};
+        const int cfg = igemm_config(p.M, p.N, p.K);      // (the 8-wave 128x128 tile has no window form: dispatch_igemm)
+        if (cfg != 0 && igemm_window_ok(p, bm[cfg], bn[cfg], esz)) return MTN_KERNEL_IGEMM_WINDOW;
+    }
+    return MTN_KERNEL_IGEMM;
+}
+
 int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
     IgemmArgs p = p0;
     p.dbg = g_igemm_dbg;

@@ -53,6 +53,7 @@ int mtn_dgrad2_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_dgrad2_tiles_m(const IgemmArgs& p);
 int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype);   // rows of the statistics slab this launch would write
 void mtn_dgrad2_set(int on);
+int mtn_igemm_family(const IgemmArgs& p, int dtype);     // MTN_KERNEL_* (include/mtn.h): the kernel mtn_igemm_run would launch
 bool mtn_pw_ok(const IgemmArgs& p, int dtype);          // pw.hip: persistent weight-stationary kernel for short-K pointwise products
 int mtn_pw_run(const IgemmArgs& p, int dtype, hipStream_t stream);
 int mtn_pw_rows(const IgemmArgs& p);                    // rows of the statistics slab it writes (one per workgroup of an n-tile)
@@ -74,6 +75,7 @@ struct WgradArgs {
     unsigned y_bytes, x_bytes;    // filled by mtn_wgrad_run: byte extents of dY / X (buffer descriptors)
     unsigned magic_ow, magic_oh;  // filled by mtn_wgrad_run: multiply-high divisors of the pixel walk
     int slab_bf16;                // filled by mtn_wgrad_run: the partial tiles are stored as bf16 (bf16 mode only)
+    int phase;                    // 0 / 3: partial tiles, then their ordered sum; 1: partial tiles only; 2: the sum only (mtn_conv_wgrad_phase)
 };
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);

@@ -1113,7 +1113,8 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
         p.x_bytes = (unsigned)((((size_t)p.B * p.H * p.W - 1) * p.ldx + p.Cin) * esz);
     }
     int rc;
-    if (row3) rc = dtype == MTN_BF16 ? launch_wgrad_row3<bf16_t>(p, stream)
+    if (p.phase == 2) rc = MTN_OK;               // (the partial tiles are in the workspace already: mtn_conv_wgrad_phase)
+    else if (row3) rc = dtype == MTN_BF16 ? launch_wgrad_row3<bf16_t>(p, stream)
                                      : (dtype == MTN_F32X3 ? launch_wgrad_row3<f32x3_t>(p, stream) : launch_wgrad_row3<float>(p, stream));
     else if (w3) {
         const unsigned w1 = (unsigned)p.W + 1u, h1 = (unsigned)p.H + 1u;
@@ -1132,7 +1133,7 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
     }
     else if (dtype == MTN_F32X3) rc = wgrad_dispatch<f32x3_t, false>(p, stream);
     else rc = wgrad_dispatch<float, false>(p, stream);
-    if (rc) return rc;
+    if (rc || p.phase == 1) return rc;
 #ifdef MTN_EXPERIMENTS
     if (g_wgrad_skip_reduce) return MTN_OK;              // (timing ablation, debug key 27: the step's result is WRONG)
 #endif

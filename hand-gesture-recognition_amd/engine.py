@@ -67,6 +67,10 @@ class Engine:
         # LayerNorm / bias gradients of the ViT are leaves: their partial-sum slabs are folded by ONE grouped call at the end
         # of the bucket instead of two launches per slab (MTN_DEFER_LEAF_SUMS=0: fold each one where it is produced)
         self.defer_leaf_sums = os.environ.get("MTN_DEFER_LEAF_SUMS", "1") != "0"
+        # the ordered sum of a weight gradient's split-K partial tiles is a leaf of the backward pass: MTN_SIDE_REDUCE=1 enqueues
+        # it on a second stream behind an event (three alternating workspaces) so that the data-gradient chain does not wait
+        # for 38 + 16 dependent ~6 us launches
+        self.side_reduce = os.environ.get("MTN_SIDE_REDUCE", "0") != "0" and self.dev.type == "cuda"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -92,9 +96,10 @@ class Engine:
 
         self.u_conv1 = unit(enc.conv1, self.H, self.W)
         self.u_conv2 = unit(enc.conv2, H2, W2)
+        self.u_conv1.tag, self.u_conv2.tag = "conv1", "conv2"
         self.stages = []
         h, w = self.H // 4, self.W // 4
-        for blk, down in enc.stage_modules():
+        for si, (blk, down) in enumerate(enc.stage_modules()):
             # st["branches"][j] = the residual blocks of branch j (cv2, cv3), each {"c1", "c2"} units
             st = {"C": blk.c_out, "h": h, "w": w}
             st["cv1"] = unit(blk.cv1, h, w)
@@ -102,10 +107,20 @@ class Engine:
                               for seq in (blk.cv2, blk.cv3)]
             st["cv4"] = unit(blk.cv4, h, w)
             st["down"] = unit(down, h, w) if down is not None else None
+            st["cv1"].tag, st["cv4"].tag = f"s{si + 1}.cv1", f"s{si + 1}.cv4"
+            if down is not None:
+                st["down"].tag = f"s{si + 1}.down"
+            for j, br in enumerate(st["branches"]):
+                for i, rb in enumerate(br):
+                    rb["c1"].tag, rb["c2"].tag = f"s{si + 1}.b{j}.{i}.c1", f"s{si + 1}.b{j}.{i}.c2"
             self.stages.append(st)
             h, w = h // 2, w // 2
         self.u_proj = unit(self.model.proj, self.fh, self.fw)
+        self.u_proj.tag = "proj"
         self.units = units
+        # TIMING ABLATIONS (tools/ablate_step.py; wrong numerics, never set by the product): tags of units whose
+        # bn_act_fwd / whole BatchNorm backward is skipped to measure what a fusion could save at most
+        self.ablate_fwd, self.ablate_bwd = frozenset(), frozenset()
 
         # ---- packed weights: descriptor table for mtn_pack_weights ---------------------------------
         flat = self.model.flat_params
@@ -202,6 +217,13 @@ class Engine:
         self.dyraw = self._new((max_dy,))
         self.bn_part = self._f32(max_part)
         self.wgrad_ws = self._f32(max_ws // 4 + 4)
+        if self.side_reduce:
+            R = 3
+            self._wg_ring = [self.wgrad_ws] + [self._f32(max_ws // 4 + 4) for _ in range(R - 1)]
+            self._wg_filled = [torch.cuda.Event() for _ in range(R)]       # phase 1 of the slot's current user is enqueued
+            self._wg_free = [None] * R                                      # phase 2 of its previous user has run
+            self._wg_i, self._wg_last = 0, None
+            self._side = torch.cuda.Stream(device=self.dev)
 
         # ---- activations and their gradients ----------------------------------------------------------
         u1, u2 = self.u_conv1, self.u_conv2
@@ -310,6 +332,8 @@ class Engine:
         bn = u.mod.bn
         self.o.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                         bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
+        if u.tag in self.ablate_fwd:
+            return
         self.o.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
 
     def _conv(self, u, x, out, training, res=None):
@@ -335,16 +359,47 @@ class Engine:
                        bn=(n.raw, nres, n.ss, n.mr, _ACT[n.act or nres is not None], self.bn_part, u.dgrad_tiles))
         n.pre_rows = u.dgrad_tiles
 
+    def _wgrad(self, x, dy, gw, k=None, s=None):
+        """weight gradient of a conv (k, s) or a Linear (k None) into ``gw``; with ``side_reduce`` its second launch -- the
+        ordered sum of the partial tiles -- runs on the side stream, and ``_join_side`` orders the main stream behind the
+        sums before anything reads the gradients."""
+        def call(ws, phase):
+            if k is None:
+                self.o.linear_wgrad(x, dy, gw, ws, phase=phase)
+            else:
+                self.o.conv_wgrad(x, dy, gw, ws, k, s, phase=phase)
+        if not self.side_reduce:
+            call(self.wgrad_ws, 3)
+            return
+        slot = self._wg_i % len(self._wg_ring)
+        self._wg_i += 1
+        main = torch.cuda.current_stream(self.dev)
+        if self._wg_free[slot] is not None:
+            main.wait_event(self._wg_free[slot])             # the sum that last read this workspace is done
+        call(self._wg_ring[slot], 1)
+        self._wg_filled[slot].record(main)
+        self._side.wait_event(self._wg_filled[slot])
+        with torch.cuda.stream(self._side):
+            call(self._wg_ring[slot], 2)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._wg_free[slot] = self._wg_last = done
+
+    def _join_side(self):
+        if self.side_reduce and self._wg_last is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._wg_last)
+
     def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True, nxt=None):
         """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res]).
         ``dres`` receives the gradient of the residual operand, added to its old contents unless
         ``dres_accumulate`` is False.  ``nxt``: see _dgrad."""
         bn, dy = u.mod.bn, self._dy(u)
         rows, u.pre_rows = u.pre_rows, 0
-        self.o.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
-                       dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
-                       partial_rows=rows)
-        self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
+        if u.tag not in self.ablate_bwd:
+            self.o.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
+                              dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
+                              partial_rows=rows)
+        self._wgrad(x, dy, self._g(u.weight), u.k, u.s)
         if g_in is not None:
             self._dgrad(u, dy, g_in, g_in_res, nxt)
 
@@ -528,7 +583,7 @@ class Engine:
         self.vit_backward(dlogits, dhm)
         up, last = self.u_proj, self.stages[-1]
         gf = self.g_feat.view(self.B, self.fh, self.fw, self.dim)
-        self.o.conv_wgrad(last["out"], gf, self._g(up.weight), self.wgrad_ws, 1, 1)
+        self._wgrad(last["out"], gf, self._g(up.weight), 1, 1)
         self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
         self._ready("head")
         self.backbone_backward(last["g_out"])
@@ -562,7 +617,7 @@ class Engine:
                 self.o.bias_grad(Gm, L["p_b2"], None)
             else:
                 self.o.bias_grad(Gm, self.row_part, g(fc2.bias))
-            self.o.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
+            self._wgrad(L["hg"], Gm, g(fc2.weight))
             if self.fuse_gelu_bwd:
                 # d a = (G @ fc2.W) * gelu'(a) and fc1's bias gradient (its column sums) in one launch
                 self.o.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
@@ -571,25 +626,30 @@ class Engine:
                 self.o.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
                 self.o.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
                 self.o.bias_grad(self.t_b, self.row_part, g(fc1.bias))
-            self.o.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
+            self._wgrad(L["xn2"], self.t_b, g(fc1.weight))
             self.o.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
             self.o.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, L["p_ln2"] if defer else self.row_part,
                               None if defer else self._pair(ln2.weight, ln2.bias), dres=Gm)
             # x1 = to_out(attention(LN(x0))) + x0
-            self.o.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
+            self._wgrad(L["ao"], Gm, g(at.to_out.weight))
             self.o.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
             self.o.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
-            self.o.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
+            self._wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight))
             self.o.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
             self.o.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
                               None if defer else self._pair(at.norm.weight, at.norm.bias), dres=Gm)
         self.o.tokens_bwd(G, self.g_feat, g(dec.cls_token))
         if self.leaf_plan is not None:
             self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches
+        if self.on_grads_ready is None:
+            self._join_side()                                           # (a decoder-only backward ends here)
 
     def _ready(self, tag):
         if self.on_grads_ready is not None:
+            self._join_side()
             self.on_grads_ready(tag)
+        elif tag == "stem":
+            self._join_side()                                 # end of the backward pass: the gradients are complete on the main stream
 
     def _pair(self, w, b):
         """Gradient slot of a (weight, bias) pair that one kernel writes as one block: the two are

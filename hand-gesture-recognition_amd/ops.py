@@ -87,6 +87,21 @@ def conv_stats_tiles(M, cout, K):
     return lib.call("mtn_conv_stats_tiles", M, cout, K)
 
 
+KERNEL_FAMILIES = {0: "igemm_kernel", 1: "igemm_kernel", 2: "igemm_kernel", 3: "pw_kernel", 4: "dgrad2_kernel", 5: "win3_kernel"}
+KERNEL_VARIANTS = {0: "streamed tiles", 1: "window", 2: "image tile", 3: "persistent pointwise", 4: "stride-2 data gradient", 5: "win3"}
+
+
+def conv_kernel_family(dtype, dgrad, B, H, W, Cin, Cout, ksize, stride, has_res=False, has_bn=False, mode=None):
+    """MTN_KERNEL_* code (include/mtn.h) of the kernel that serves this conv / Linear-shaped product under the launch rules of
+    the loaded library (no launch): dgrad=False forward (a Linear is B = rows, H = W = 1, ksize = stride = 1), True data
+    gradient given the geometry of the FORWARD conv.  Profilers and bench.py label their per-family figures with it."""
+    code = lib.call("mtn_conv_kernel_family", code_of(dtype, mode), int(bool(dgrad)), B, H, W, Cin, Cout, ksize, stride,
+                    int(bool(has_res)), int(bool(has_bn)))
+    if code < 0:
+        raise RuntimeError(f"mtn_conv_kernel_family: {lib.get().mtn_last_error().decode()}")
+    return code
+
+
 def conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
     """rows of the partial-statistics slab conv_fwd writes for this layer geometry."""
     return lib.call("mtn_conv_fwd_stats_tiles", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
@@ -191,30 +206,36 @@ def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride, mode=No
     return lib.call("mtn_conv_wgrad_workspace_bytes", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
-def conv_wgrad(x, dy, dw, workspace, ksize, stride, mode=None):
-    """x [B,H,W,Cin], dy [B,OH,OW,Cout] -> dw f32 [Cout,Cin,k,k] (overwritten)."""
+def conv_wgrad(x, dy, dw, workspace, ksize, stride, mode=None, phase=3):
+    """x [B,H,W,Cin], dy [B,OH,OW,Cout] -> dw f32 [Cout,Cin,k,k] (overwritten).  ``phase``: 1 = only the split-K partial
+    tiles into ``workspace``, 2 = only their ordered sum into ``dw`` (enqueued on the CURRENT stream: the caller orders it
+    behind phase 1), 3 = both."""
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
     xp, ldx = _rows(x)
     dyp, lddy = _rows(dy)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
-    lib.call("mtn_conv_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
+    lib.call("mtn_conv_wgrad_phase", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
              workspace.numel() * workspace.element_size(), dtype_code(x, mode), B, H, W, Cin, Cout,
-             ksize, stride, _stream(x))
+             ksize, stride, phase, _stream(x))
 
 
 def linear_wgrad_workspace_bytes(dtype, M, N, K, mode=None):
     return lib.call("mtn_linear_wgrad_workspace_bytes", code_of(dtype, mode), M, N, K)
 
 
-def linear_wgrad(x, dy, dw, workspace, mode=None):
-    """dw[N,K] = dy[M,N]^T @ x[M,K] (f32, overwritten)."""
+def linear_wgrad(x, dy, dw, workspace, mode=None, phase=3):
+    """dw[N,K] = dy[M,N]^T @ x[M,K] (f32, overwritten); ``phase`` as in conv_wgrad."""
     K, N = x.shape[-1], dy.shape[-1]
     M = x.numel() // K
     xp, ldx = _rows(x)
     dyp, lddy = _rows(dy)
-    lib.call("mtn_linear_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
-             workspace.numel() * workspace.element_size(), dtype_code(x, mode), M, N, K, _stream(x))
+    if phase == 3:
+        lib.call("mtn_linear_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
+                 workspace.numel() * workspace.element_size(), dtype_code(x, mode), M, N, K, _stream(x))
+    else:      # (a Linear is one image of width M: include/mtn.h)
+        lib.call("mtn_conv_wgrad_phase", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
+                 workspace.numel() * workspace.element_size(), dtype_code(x, mode), 1, 1, M, K, N, 1, 1, phase, _stream(x))
 
 
 def slab_rows(rows):

@@ -147,6 +147,13 @@ size_t mtn_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int Cin, i
 int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                    size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
                    int stride, void* stream);
+/* (ABI 6) the two launches of mtn_conv_wgrad separately: phase 1 = the split-K partial tiles into `workspace` only (dw
+ * unused), phase 2 = their ordered sum into dw only (x, dy unused; same geometry arguments, same workspace), phase 3 = both
+ * (= mtn_conv_wgrad).  The sum is a leaf of the backward pass: a caller may enqueue phase 2 on another stream behind an
+ * event and keep the data-gradient chain going (engine.py, MTN_SIDE_REDUCE).  A Linear is B = 1, H = 1, W = rows, ksize 1. */
+int mtn_conv_wgrad_phase(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                         size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
+                         int stride, int phase, void* stream);
 size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
 int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                      size_t ws_bytes, int dtype, int M, int N, int K, void* stream);
@@ -338,6 +345,24 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  * -DMTN_STAMPS only; returns non-zero otherwise). */
 int mtn_debug_set(int key, int value);
 int mtn_debug_read(int key, void* dst, size_t bytes);
+/* (ABI 6) 1 iff this build contains the measured-and-rejected kernel variants (-DMTN_EXPERIMENTS: the CPU executor
+ * library of the tests, diagnostic GPU builds); the product library returns 0.  mtn_debug_key_is_experiment: 1 iff
+ * mtn_debug_set(key, value) selects such a variant (it is refused on a build without them) -- the test suite uses it to
+ * keep the experiment-only parametrisations out of a product-library run instead of skipping them one by one. */
+int mtn_has_experiments(void);
+int mtn_debug_key_is_experiment(int key, int value);
+/* (ABI 6) which kernel source serves a conv / Linear-shaped product under the launch rules of this build, for profilers
+ * and bench.py's per-family roofline (no launch, no pointers): dgrad = 0 forward (a Linear is B = rows, H = W = 1,
+ * ksize = stride = 1), 1 data gradient (geometry of the FORWARD conv); has_res / has_bn: the call has a second epilogue
+ * operand / a BatchNorm-backward hand-over.  Returns MTN_KERNEL_*, or -1 on bad arguments. */
+#define MTN_KERNEL_IGEMM 0        /* igemm_kernel, streamed A and W tiles */
+#define MTN_KERNEL_IGEMM_WINDOW 1 /* igemm_kernel, stride-1 3x3 window mode */
+#define MTN_KERNEL_IGEMM_IMAGE 2  /* igemm_kernel, one image per tile (stage-3 3x3 layers) */
+#define MTN_KERNEL_PW 3           /* pw_kernel: persistent weight-stationary pointwise walk */
+#define MTN_KERNEL_DGRAD2 4       /* dgrad2_kernel: 3x3 stride-2 data gradient */
+#define MTN_KERNEL_WIN3 5         /* win3_kernel (experiments builds only) */
+int mtn_conv_kernel_family(int dtype, int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                           int has_res, int has_bn);
 
 #ifdef __cplusplus
 }

@@ -109,10 +109,18 @@ def Fl(t):
     return join_x3(t) if (t.dtype == torch.float32 and x3_active()) else t.float()
 
 
+# set by conftest's autouse fixture for the duration of one test: [True] once the test selected an experiment-only variant
+_saw_experiment = [False]
+
+
 def dbg(key, value):
     """mtn_debug_set(key, value); a value that selects a measured-and-rejected kernel variant exists only in -DMTN_EXPERIMENTS
-    builds (the CPU executor library): on the product library the test is skipped, not failed."""
+    builds (the CPU executor library).  Parametrisations that do so carry the ``experiments`` marker (tests/experiment_ids.txt,
+    kept in step by conftest.py) and are DESELECTED when the library under test has no experiments, so a product-library
+    run shows no skips for them; one that is not on the list yet still skips here -- visibly -- rather than fail."""
     from hand_gesture_recognition_amd import lib
+    if lib.call("mtn_debug_key_is_experiment", key, value):
+        _saw_experiment[0] = True
     try:
         lib.call("mtn_debug_set", key, value)
     except RuntimeError as e:

@@ -97,6 +97,7 @@ def test_bn_finalize_many_tile_rows(be, R, C):
     assert rel_err(rv, 0.9 + 0.1 * var * count / (count - 1)) < 1e-6
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("R,C", [(700, 64), (257, 512), (4608, 128), (18432, 64), (1000, 72)])
 def test_bn_fold_finalize_one_launch_is_the_two_launch_result(be, R, C):
     """Round 4, measured and not adopted (profiles/r04_tail_ab.txt; -DMTN_EXPERIMENTS builds, debug key 26 = 1): rowblock_sum +
@@ -130,6 +131,7 @@ def test_bn_fold_finalize_one_launch_is_the_two_launch_result(be, R, C):
     assert int(got[(1, 0)][4]) == 1 and torch.isfinite(got[(1, 0)][0]).all()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("M,C", [(40000, 64), (17000, 256)])
 def test_bn_bwd_fold_finalize_one_launch_is_the_two_launch_result(be, M, C):
     g = torch.Generator().manual_seed(M)
@@ -168,9 +170,7 @@ def test_bias_grad_many_slab_rows(be):
     assert rel_err(db, x.double().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("fused_s2", [1, 0], ids=["dgrad2", "igemm"])
-@pytest.mark.parametrize("cfg", [
+_HANDOVER_CFGS = [
     # B, H, W, Cin, Cout, k, s, act, dgrad residual, BatchNorm-unit residual
     (2, 6, 6, 64, 64, 3, 1, True, False, False),
     (3, 5, 7, 128, 128, 1, 1, True, True, True),        # the c1 -> first-block c2 hand-over (both residuals)
@@ -178,14 +178,18 @@ def test_bias_grad_many_slab_rows(be):
     (1, 8, 8, 64, 128, 3, 2, True, False, False),       # stride 2 (dgrad2 / parity-major rows)
     (3, 12, 20, 128, 256, 3, 2, True, True, False),     # stride 2, several tiles
     (2, 12, 12, 256, 64, 1, 1, True, False, True),
-])
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+# (fused_s2 = 0 -- igemm's parity-major rows instead of dgrad2 -- only exists for the stride-2 shapes)
+@pytest.mark.parametrize("fused_s2,cfg", [pytest.param(1, c, id=f"dgrad2-cfg{i}") for i, c in enumerate(_HANDOVER_CFGS)] +
+                         [pytest.param(0, c, id=f"igemm-cfg{i}") for i, c in enumerate(_HANDOVER_CFGS) if c[6] == 2])
 def test_conv_dgrad_writes_the_bn_backward_sums(be, dtype, fused_s2, cfg):
     """mtn_conv_dgrad_bn: dx equals the plain data gradient, its slab sums to (sum dz, sum dz*xhat) of
     the unit consuming dx, and bn_act_bwd(partial_rows=tiles) equals the two-pass backward."""
     from hand_gesture_recognition_amd import lib
     B, H, W, Cin, Cout, k, s, act, with_res, with_bres = cfg
-    if s == 1 and not fused_s2:
-        pytest.skip("the switch only matters for stride 2")
     d = be.device
     w = _rand((Cout, Cin, k, k), torch.float32, 41) / (Cout * k * k) ** 0.5
     wt = A(w.permute(1, 2, 3, 0).contiguous().to(dtype)).to(d)

@@ -306,8 +306,9 @@ def test_linear_bias_gelu_residual(be, stages, dtype):
     assert rel_err(Fl(out), ref) < tol(dtype)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tr16", [0, 1, 2])       # 0: scalar column reads, 1: ds_read_tr16 (register staged), 2: LDS-DMA (default)
+# tr16: 0 = scalar column reads (bf16 only: the switch does nothing for 4-byte elements), 1 = ds_read_tr16 (register staged), 2 = LDS-DMA (default)
+@pytest.mark.parametrize("dtype,tr16", [pytest.param(d.values[0], t, id=f"{t}-{d.id}", marks=d.marks) for d in DTYPES for t in (0, 1, 2)
+                                        if not (d.values[0] == torch.float32 and t == 0)])
 @pytest.mark.parametrize("cfg", [
     (2, 6, 6, 64, 64, 3, 1),
     (1, 8, 8, 64, 128, 3, 2),
@@ -317,8 +318,6 @@ def test_linear_bias_gelu_residual(be, stages, dtype):
 ])
 def test_conv_wgrad(be, dtype, tr16, cfg):
     from hand_gesture_recognition_amd import lib
-    if dtype == torch.float32 and tr16 == 0:
-        pytest.skip("tr16 only affects bf16")
     dbg(5, 1 if tr16 == 2 else 0)
     B, H, W, Cin, Cout, k, s = cfg
     x = _rand((B, H, W, Cin), dtype, 12)

@@ -259,7 +259,15 @@ def test_bench_two_rank_code_path_rehearsal(launcher):
     rk = out["ranks"]
     assert rk["backend"] == "gloo" and len(rk["ms_per_step_per_rank"]) == 2 and rk["buckets"] == 5
     assert rk["gradient_bytes_all_reduced"] == 7409000 * 4 and rk["comm_exposed_ms"] >= 0
-    assert out["roofline"]["launches_per_step"] == 69
+    # the number of ranks as an all-reduce counted them, and the N = 1 figure measured in the
+    # same processes through the same bucketed path (what the first real SCALE run is checked against)
+    assert rk["rccl_ranks"] == 2 and rk["n1_same_processes"]["images_per_sec_per_gpu"] > 0
+    assert rk["n1_same_processes"]["ms_per_step_max_over_ranks"] > 0
+    # 69 conv-forward / conv-data-gradient / Linear calls per step: 64 igemm_kernel launches, 5 pw_kernel (own family); the
+    # three stride-2 data gradients (dgrad2_kernel) are counted apart from the 69
+    fam = out["roofline"]["families"]
+    assert out["roofline"]["launches_per_step"] == 64 and fam["pointwise_persistent"]["launches_per_step"] == 5
+    assert fam["conv3x3_stride2_dgrad"]["launches_per_step"] == 3 and fam["conv3x3"]["launches_per_step"] + fam["pointwise"]["launches_per_step"] == 64
 
 
 def test_bench_self_launch_propagates_failure():

@@ -7,9 +7,10 @@ weight gradients, the one-class tap shortcut of the stride-2 data gradients) mee
             worst gradient tensor, so 1e-3 is a meaningful bar for both fp32-storage modes (exact-f32 MFMA and
             split-bf16 "bf16x3"); the bf16 throughput mode is held to per-family bounds taken from
             profiles/r03_grad_errors_f64_b256.txt (tools/grad_error_table.py).
-  config 4  MultiTaskNet 384x384 (577 tokens), B=128, fp32 oracle.
+  config 4  MultiTaskNet 384x384 (577 tokens), B=128: truth = the oracle in float64 as for config 2 (round 5: the fp32
+            oracle's own distance from it is measured in the same fixture and printed, not assumed).
   config 5  GELAN backbone only, B=512, synthetic upstream gradient, fp32 oracle.
-Host memory: the float64 oracle at B=256 keeps ~40 GB of autograd state, config 4 / 5 ~40 GB in fp32.
+Host memory: the float64 oracle at B=256 keeps ~40 GB of autograd state, config 4 ~80 GB in float64, config 5 ~40 GB in fp32.
 """
 import gc
 
@@ -104,27 +105,38 @@ def test_config2_b256_vs_float64_oracle(truth_config2, mode):
 
 
 @pytest.fixture(scope="module")
-def ref_config4():
-    """fp32 oracle at B=128, 384x384 (577 tokens)."""
+def truth_config4():
+    """float64 oracle at B=128, 384x384 (577 tokens), and how far the fp32 oracle -- the reference's own arithmetic -- is
+    from it on the worst gradient tensor of each family (printed: the noise floor the 1e-3 gradient gates sit on)."""
     _threads()
     sd = O.synthetic_state_dict(21, 19, seed=0)
     batch = O.synthetic_batch(128, 384, seed=42)
-    outs, losses, grads = O.forward_backward({k: v.clone() for k, v in sd.items()}, batch)
+    _, _, g32 = O.forward_backward({k: v.clone() for k, v in sd.items()}, batch)
+    gc.collect()
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    b64 = tuple(t.double() if t.dtype.is_floating_point else t for t in batch)
+    outs, losses, grads = O.forward_backward(sd64, b64)
+    del sd64, b64
+    worst = {"backbone": (0.0, ""), "vit": (0.0, "")}
+    for k, g in g32.items():
+        e = rel_err(g, grads[k])
+        if e > worst[family(k)][0]:
+            worst[family(k)] = (e, k)
+    print(f"[fp32 oracle vs float64 oracle, config 4] worst gradient tensors: backbone {worst['backbone'][0]:.2e} "
+          f"({worst['backbone'][1]}), vit {worst['vit'][0]:.2e} ({worst['vit'][1]})")
+    del g32
     gc.collect()
     return sd, batch, outs, losses, grads
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
-def test_config4_b128_384_vs_oracle(ref_config4, mode):
+def test_config4_b128_384_vs_oracle(truth_config4, mode):
+    """Both fp32-storage modes at 1e-3 on outputs, losses AND gradients against the float64 truth (round 4 compared with the
+    fp32 oracle and had widened the split-bf16 gradient bound to 1.5e-3: restored)."""
     be = Backend("hip")
-    sd, batch, outs, losses, grads = ref_config4
+    sd, batch, outs, losses, grads = truth_config4
     m, o, l = _run_model(sd, batch, 384, mode, be.device)
-    # split-bf16 gradients at this size: 1.5e-3 against the FP32 oracle (observed 1.02e-3 on a stage-1 BatchNorm weight; round 3:
-    # 7.1e-4).  Two things changed in round 4 -- the 577-token attention runs on split-bf16 products too (it used to fall back
-    # to exact-f32 kernels because its padded rows did not fit LDS), and elementwise consumers see every stored tensor rounded
-    # to hi + lo (2^-18) -- and the fp32 oracle is itself 1e-4 .. 8e-4 from a float64 run on such tensors (DESIGN.md 2b).
-    # Outputs and losses stay at 1e-3.
-    _check(m, o, l, outs, losses, grads, mode, bounds=(1e-3, 1.5e-3, 1e-3) if mode == "bf16x3" else None)
+    _check(m, o, l, outs, losses, grads, mode)
     del m
     torch.cuda.empty_cache()
 

@@ -165,17 +165,20 @@ def test_cls_head(be, dtype):
     assert rel_err(dlnwb[0], ps[0].grad) < 1e-4 and rel_err(dlnwb[1], ps[1].grad) < 1e-4
 
 
+_POSE_CFGS = [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17),
+              (2, 6, 6, 21), (1, 3, 6, 17), (1, 24, 24, 21), (3, 5, 12, 21),   # widths 6 / 12 / 24: the row-streaming kernels
+              (1, 8, 6, 21), (2, 12, 6, 17), (1, 7, 6, 21), (3, 13, 12, 21),    # ... cut into 2 / 4 bands per image
+              (1, 2, 26, 17), (1, 1, 28, 21)]   # maps wider than 24: the general (round-1) kernels, the only ones that take them
+
+
 @pytest.mark.parametrize("dtype", GEMM_DTYPES)      # (x3: the pose head takes PLAIN f32 tokens and multiplies split-bf16)
-@pytest.mark.parametrize("cfg", [(2, 2, 2, 21), (1, 3, 5, 21), (8, 1, 2, 21), (2, 12, 12, 21), (1, 2, 3, 17),
-                                 (2, 6, 6, 21), (1, 3, 6, 17), (1, 24, 24, 21), (3, 5, 12, 21),   # widths 6 / 12 / 24: the row-streaming kernels
-                                 (1, 8, 6, 21), (2, 12, 6, 17), (1, 7, 6, 21), (3, 13, 12, 21)])   # ... cut into 2 / 4 bands per image
-@pytest.mark.parametrize("bands", [0, 1])            # debug key 25: 0 = bands by batch size, 1 = one workgroup per image
+# debug key 25: 0 = bands by batch size, 1 = one workgroup per image -- a choice only where the banded kernel applies
+@pytest.mark.parametrize("cfg,bands", [pytest.param(c, b, id=f"cfg{i}-{b}") for i, c in enumerate(_POSE_CFGS) for b in (0, 1)
+                                       if b == 0 or (c[2] in (6, 12, 24) and c[1] >= 6)])
 def test_pose_head(be, dtype, cfg, bands):
     B, h, w, J = cfg
     if be.name == "emu" and h * w > 80:
         pytest.skip("full-size map on the GPU only")
-    if bands == 1 and (w not in (6, 12, 24) or h < 6):
-        pytest.skip("no bands at this size either way")
     dbg(25, bands)
     d = be.device
     tok = _rand((B, h * w + 1, 256), dtype, 20)

@@ -22,14 +22,20 @@ ap.add_argument("--steps", type=int, default=120)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--size", type=int, default=192)
 ap.add_argument("--lr", type=float, default=1e-3)
+ap.add_argument("--bf16-f32-slabs", action="store_true",
+                help="also run the bf16 mode with f32 split-K partial tiles (debug key 28 = 0): ADVICE round 4 asked which of the two "
+                     "slab types the lr 1e-3 spike of the bf16 curve belongs to")
+ap.add_argument("--no-oracle", action="store_true", help="skip the two CPU oracle runs: deviations are then measured against HIP fp32")
 a = ap.parse_args()
+if a.bf16_f32_slabs:
+    os.environ["MTN_ALLOW_DEBUG_KEYS"] = "1"
 dev = torch.device("cuda", 0)
 torch.set_num_threads(min(16, os.cpu_count() or 1))
 batches = [O.synthetic_batch(a.batch, a.size, seed=100 + i) for i in range(4)]
 
 curves = {}
 t0 = time.time()
-for name, f64 in (("oracle f64 (truth)", True), ("oracle fp32 (CPU)", False)):
+for name, f64 in (() if a.no_oracle else (("oracle f64 (truth)", True), ("oracle fp32 (CPU)", False))):
     sd = O.synthetic_state_dict(21, 19, seed=7)
     bs = batches
     if f64:
@@ -41,7 +47,13 @@ for name, f64 in (("oracle f64 (truth)", True), ("oracle fp32 (CPU)", False)):
         _, losses, _ = O.train_step(sd, bs[i % 4], st, a.lr)
         curves[name].append([float(x) for x in losses])
 t_cpu = time.time() - t0
-for name, dt in (("HIP fp32", torch.float32), ("HIP bf16x3", "bf16x3"), ("HIP bf16", torch.bfloat16)):
+from hand_gesture_recognition_amd import lib  # noqa: E402
+runs = [("HIP fp32", torch.float32, None), ("HIP bf16x3", "bf16x3", None), ("HIP bf16", torch.bfloat16, None)]
+if a.bf16_f32_slabs:
+    runs.append(("HIP bf16, f32 slabs", torch.bfloat16, 0))
+for name, dt, key28 in runs:
+    if key28 is not None:
+        lib.call("mtn_debug_set", 28, key28)
     model = MultiTaskNet(21, 19, [a.size, a.size], compute_dtype=dt)
     model.load_state_dict(O.synthetic_state_dict(21, 19, seed=7), strict=True)
     model.to(dev).train()
@@ -50,15 +62,18 @@ for name, dt in (("HIP fp32", torch.float32), ("HIP bf16x3", "bf16x3"), ("HIP bf
     curves[name] = []
     for i in range(a.steps):
         curves[name].append([float(x) for x in step(*dbs[i % 4]).cpu()])
+    if key28 is not None:
+        lib.call("mtn_debug_set", 28, 1)
 
-ref = curves["oracle f64 (truth)"]
+truth = "HIP fp32" if a.no_oracle else "oracle f64 (truth)"
+ref = curves[truth]
 print(f"# {a.steps} AdamW steps (lr {a.lr}), B={a.batch}, {a.size}x{a.size}, 4 synthetic batches cycled; both oracle runs on {torch.get_num_threads()} CPU threads: {t_cpu:.0f} s")
 print(f"{'step':>5s} " + " ".join(f"{k:>20s}" for k in curves) + "    (total loss = 0.001*CE + JointsMSE)")
 for i in sorted(set(list(range(0, a.steps, max(1, a.steps // 12))) + [a.steps - 1])):
     print(f"{i:5d} " + " ".join(f"{curves[k][i][0]:20.6f}" for k in curves))
-print("# relative deviation of the total loss from the float64 oracle: over the first 25 % / 50 % / 100 % of the run, and the first step it exceeds 1e-3 / 1e-2")
+print(f"# relative deviation of the total loss from {truth}: over the first 25 % / 50 % / 100 % of the run, and the first step it exceeds 1e-3 / 1e-2")
 for k in curves:
-    if k == "oracle f64 (truth)":
+    if k == truth:
         continue
     d = [abs(c[0] - r[0]) / abs(r[0]) for c, r in zip(curves[k], ref)]
     first = lambda t: next((i for i, v in enumerate(d) if v > t), None)
