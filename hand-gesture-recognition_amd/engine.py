@@ -67,10 +67,10 @@ class Engine:
         # LayerNorm / bias gradients of the ViT are leaves: their partial-sum slabs are folded by ONE grouped call at the end
         # of the bucket instead of two launches per slab (MTN_DEFER_LEAF_SUMS=0: fold each one where it is produced)
         self.defer_leaf_sums = os.environ.get("MTN_DEFER_LEAF_SUMS", "1") != "0"
-        # the ordered sum of a weight gradient's split-K partial tiles is a leaf of the backward pass: MTN_SIDE_REDUCE=1 enqueues
-        # it on a second stream behind an event (three alternating workspaces) so that the data-gradient chain does not wait
-        # for 38 + 16 dependent ~6 us launches
-        self.side_reduce = os.environ.get("MTN_SIDE_REDUCE", "0") != "0" and self.dev.type == "cuda"
+        # consumer-side BatchNorm apply for the `t` tensor of a residual block (c1 -> c2, nothing else reads it): c1
+        # stores only its raw output, c2's forward (window / image-tile kernel) and c2's weight gradient (window kernel) apply
+        # SiLU(raw * scale + shift) to their operand in LDS -- no bn_act_fwd launch, no activated copy (MTN_FUSE_T=0: off)
+        self.fuse_t = os.environ.get("MTN_FUSE_T", "1") != "0"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -107,6 +107,12 @@ class Engine:
                               for seq in (blk.cv2, blk.cv3)]
             st["cv4"] = unit(blk.cv4, h, w)
             st["down"] = unit(down, h, w) if down is not None else None
+            for br in st["branches"]:
+                for rb in br:
+                    c2 = rb["c2"]
+                    geom = (self.dt, B, c2.hin, c2.win, c2.cin, c2.cout, c2.k, c2.s)
+                    rb["fuse_t"] = bool(self.fuse_t and c2.k == 3 and c2.s == 1 and self.o.conv_fwd_bn_in_ok(*geom)
+                                        and self.o.conv_wgrad_family(*geom) == 1)
             st["cv1"].tag, st["cv4"].tag = f"s{si + 1}.cv1", f"s{si + 1}.cv4"
             if down is not None:
                 st["down"].tag = f"s{si + 1}.down"
@@ -217,13 +223,6 @@ class Engine:
         self.dyraw = self._new((max_dy,))
         self.bn_part = self._f32(max_part)
         self.wgrad_ws = self._f32(max_ws // 4 + 4)
-        if self.side_reduce:
-            R = 3
-            self._wg_ring = [self.wgrad_ws] + [self._f32(max_ws // 4 + 4) for _ in range(R - 1)]
-            self._wg_filled = [torch.cuda.Event() for _ in range(R)]       # phase 1 of the slot's current user is enqueued
-            self._wg_free = [None] * R                                      # phase 2 of its previous user has run
-            self._wg_i, self._wg_last = 0, None
-            self._side = torch.cuda.Stream(device=self.dev)
 
         # ---- activations and their gradients ----------------------------------------------------------
         u1, u2 = self.u_conv1, self.u_conv2
@@ -332,17 +331,19 @@ class Engine:
         bn = u.mod.bn
         self.o.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                         bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
-        if u.tag in self.ablate_fwd:
+        if out is None or u.tag in self.ablate_fwd:
             return
         self.o.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
 
-    def _conv(self, u, x, out, training, res=None):
-        """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87)"""
+    def _conv(self, u, x, out, training, res=None, in_ss=None):
+        """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87).  Training only: ``in_ss`` -- x is the raw output of the
+        unit before and the kernel applies that unit's BatchNorm + SiLU itself; ``out`` None -- leave only u.raw and u.ss
+        (the consumer applies them)."""
         if not training:
             # eval(): BatchNorm folded into the weights (pack_weights(folded=True)) and an epilogue bias: one launch
             self.o.conv_bias_act_fwd(x, u.wf, u.ss[1], out, _ACT[u.act or res is not None], u.k, u.s, res=res)
             return
-        self.o.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles)
+        self.o.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles, in_ss=in_ss)
         self._bn_fwd(u, out, res)
 
     def _dgrad(self, u, dy, g_in, g_in_res=None, nxt=None):
@@ -359,47 +360,17 @@ class Engine:
                        bn=(n.raw, nres, n.ss, n.mr, _ACT[n.act or nres is not None], self.bn_part, u.dgrad_tiles))
         n.pre_rows = u.dgrad_tiles
 
-    def _wgrad(self, x, dy, gw, k=None, s=None):
-        """weight gradient of a conv (k, s) or a Linear (k None) into ``gw``; with ``side_reduce`` its second launch -- the
-        ordered sum of the partial tiles -- runs on the side stream, and ``_join_side`` orders the main stream behind the
-        sums before anything reads the gradients."""
-        def call(ws, phase):
-            if k is None:
-                self.o.linear_wgrad(x, dy, gw, ws, phase=phase)
-            else:
-                self.o.conv_wgrad(x, dy, gw, ws, k, s, phase=phase)
-        if not self.side_reduce:
-            call(self.wgrad_ws, 3)
-            return
-        slot = self._wg_i % len(self._wg_ring)
-        self._wg_i += 1
-        main = torch.cuda.current_stream(self.dev)
-        if self._wg_free[slot] is not None:
-            main.wait_event(self._wg_free[slot])             # the sum that last read this workspace is done
-        call(self._wg_ring[slot], 1)
-        self._wg_filled[slot].record(main)
-        self._side.wait_event(self._wg_filled[slot])
-        with torch.cuda.stream(self._side):
-            call(self._wg_ring[slot], 2)
-            done = torch.cuda.Event()
-            done.record(self._side)
-        self._wg_free[slot] = self._wg_last = done
-
-    def _join_side(self):
-        if self.side_reduce and self._wg_last is not None:
-            torch.cuda.current_stream(self.dev).wait_event(self._wg_last)
-
-    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True, nxt=None):
+    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True, nxt=None, x_ss=None):
         """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res]).
         ``dres`` receives the gradient of the residual operand, added to its old contents unless
-        ``dres_accumulate`` is False.  ``nxt``: see _dgrad."""
+        ``dres_accumulate`` is False.  ``nxt``: see _dgrad.  ``x_ss``: x is a raw output, see _conv(in_ss=...)."""
         bn, dy = u.mod.bn, self._dy(u)
         rows, u.pre_rows = u.pre_rows, 0
         if u.tag not in self.ablate_bwd:
             self.o.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
                               dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
                               partial_rows=rows)
-        self._wgrad(x, dy, self._g(u.weight), u.k, u.s)
+        self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s, in_ss=x_ss)
         if g_in is not None:
             self._dgrad(u, dy, g_in, g_in_res, nxt)
 
@@ -440,8 +411,12 @@ class Engine:
                 xin = cat[..., h2 * (j + 1):h2 * (j + 2)]
                 for i, rb in enumerate(br):
                     out = cat[..., h2 * (j + 2):h2 * (j + 3)] if i + 1 == len(br) else rb["o"]
-                    self._conv(rb["c1"], xin, rb["t"], training)
-                    self._conv(rb["c2"], rb["t"], out, training, res=xin)
+                    if training and rb["fuse_t"]:
+                        self._conv(rb["c1"], xin, None, training)
+                        self._conv(rb["c2"], rb["c1"].raw, out, training, res=xin, in_ss=rb["c1"].ss)
+                    else:
+                        self._conv(rb["c1"], xin, rb["t"], training)
+                        self._conv(rb["c2"], rb["t"], out, training, res=xin)
                     xin = out
             self._conv(st["cv4"], cat, st["out"], training)
             cur = st["out"]
@@ -539,8 +514,9 @@ class Engine:
                     first = i == 0
                     xin = cat[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["o"]
                     g_xin = gc[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["g_o"]
-                    self._conv_bwd(rb["c2"], g_out, rb["t"], st["g_t"], res=xin, dres=g_xin, dres_accumulate=first,
-                                   nxt=(rb["c1"], None))
+                    fz = rb["fuse_t"]
+                    self._conv_bwd(rb["c2"], g_out, rb["c1"].raw if fz else rb["t"], st["g_t"], res=xin, dres=g_xin,
+                                   dres_accumulate=first, nxt=(rb["c1"], None), x_ss=rb["c1"].ss if fz else None)
                     # g_xin is complete after c1's data gradient, except the y1 slice of the concat (branch 0, first
                     # block), which is only half of cv1's output gradient.  Its consumer: the previous block's c2,
                     # or -- for the y2 slice (branch 1, first block) -- the last block of branch 0
@@ -583,7 +559,7 @@ class Engine:
         self.vit_backward(dlogits, dhm)
         up, last = self.u_proj, self.stages[-1]
         gf = self.g_feat.view(self.B, self.fh, self.fw, self.dim)
-        self._wgrad(last["out"], gf, self._g(up.weight), 1, 1)
+        self.o.conv_wgrad(last["out"], gf, self._g(up.weight), self.wgrad_ws, 1, 1)
         self._dgrad(up, gf, last["g_out"], None, nxt=(last["cv4"], None))
         self._ready("head")
         self.backbone_backward(last["g_out"])
@@ -617,7 +593,7 @@ class Engine:
                 self.o.bias_grad(Gm, L["p_b2"], None)
             else:
                 self.o.bias_grad(Gm, self.row_part, g(fc2.bias))
-            self._wgrad(L["hg"], Gm, g(fc2.weight))
+            self.o.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
             if self.fuse_gelu_bwd:
                 # d a = (G @ fc2.W) * gelu'(a) and fc1's bias gradient (its column sums) in one launch
                 self.o.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
@@ -626,30 +602,25 @@ class Engine:
                 self.o.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
                 self.o.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
                 self.o.bias_grad(self.t_b, self.row_part, g(fc1.bias))
-            self._wgrad(L["xn2"], self.t_b, g(fc1.weight))
+            self.o.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
             self.o.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
             self.o.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, L["p_ln2"] if defer else self.row_part,
                               None if defer else self._pair(ln2.weight, ln2.bias), dres=Gm)
             # x1 = to_out(attention(LN(x0))) + x0
-            self._wgrad(L["ao"], Gm, g(at.to_out.weight))
+            self.o.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
             self.o.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
             self.o.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
-            self._wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight))
+            self.o.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
             self.o.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
             self.o.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
                               None if defer else self._pair(at.norm.weight, at.norm.bias), dres=Gm)
         self.o.tokens_bwd(G, self.g_feat, g(dec.cls_token))
         if self.leaf_plan is not None:
             self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches
-        if self.on_grads_ready is None:
-            self._join_side()                                           # (a decoder-only backward ends here)
 
     def _ready(self, tag):
         if self.on_grads_ready is not None:
-            self._join_side()
             self.on_grads_ready(tag)
-        elif tag == "stem":
-            self._join_side()                                 # end of the backward pass: the gradients are complete on the main stream
 
     def _pair(self, w, b):
         """Gradient slot of a (weight, bias) pair that one kernel writes as one block: the two are
