@@ -60,19 +60,6 @@ int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float*
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
-int mtn_conv_fwd_bn_in(const void* x, int ldx, const float* in_scale_shift, const void* w, void* y, int ldy, float* stats,
-                       int stats_tiles, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
-    IgemmArgs p{};
-    const int rc = conv_fwd_args(p, "conv_fwd_bn_in", B, H, W, Cin, Cout, ksize, stride);
-    if (rc) return rc;
-    MTN_REQUIRE(in_scale_shift, "conv_fwd_bn_in: null scale / shift");
-    p.A = x; p.Wp = w; p.Out = y; p.lda = ldx; p.ldc = ldy;
-    p.stats = stats;
-    p.stats_rows = stats_tiles;
-    p.a_ss = in_scale_shift;
-    return mtn_igemm_run(p, dtype, (hipStream_t)stream);
-}
-
 int mtn_conv_bias_act_fwd(const void* x, int ldx, const void* w, const float* bias, int act, const void* res, int ldres,
                           void* y, int ldy, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                           void* stream) {
@@ -208,28 +195,6 @@ int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, 
     if (conv_wgrad_args(p, dtype, B, H, W, Cin, Cout, ksize, stride)) return MTN_ERR_BAD_ARG;
     MTN_REQUIRE(ws_bytes >= (size_t)p.splits * p.N * p.K * sizeof(float), "conv_wgrad: workspace too small");
     p.dY = dy; p.lddy = lddy; p.X = x; p.ldx = ldx; p.partial = (float*)workspace; p.dW = dw;
-    return mtn_wgrad_run(p, dtype, (hipStream_t)stream);
-}
-
-int mtn_conv_wgrad_family(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
-    WgradArgs p{};
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) { mtn_set_error("conv_wgrad_family: ksize=%d stride=%d", ksize, stride); return -1; }
-    if (conv_wgrad_args(p, dtype, B, H, W, Cin, Cout, ksize, stride)) return -1;
-    return p.win;
-}
-
-int mtn_conv_wgrad_bn_in(const void* x, int ldx, const float* in_scale_shift, const void* dy, int lddy, float* dw, void* workspace,
-                         size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
-    MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_wgrad_bn_in: ksize=%d", ksize);
-    MTN_REQUIRE(stride == 1 || stride == 2, "conv_wgrad_bn_in: stride=%d", stride);
-    WgradArgs p{};
-    if (conv_wgrad_args(p, dtype, B, H, W, Cin, Cout, ksize, stride)) return MTN_ERR_BAD_ARG;
-    MTN_REQUIRE(p.win == 1, "conv_wgrad_bn_in: the consumer-side BatchNorm apply exists for the 3x3 stride-1 window kernel only "
-                "(mtn_conv_wgrad_family = %d for this shape)", p.win);
-    MTN_REQUIRE(in_scale_shift && (uintptr_t)in_scale_shift % 16 == 0, "conv_wgrad_bn_in: scale / shift must be non-null and 16-byte aligned");
-    MTN_REQUIRE(ws_bytes >= (size_t)p.splits * p.N * p.K * sizeof(float), "conv_wgrad_bn_in: workspace too small");
-    p.dY = dy; p.lddy = lddy; p.X = x; p.ldx = ldx; p.partial = (float*)workspace; p.dW = dw;
-    p.x_ss = in_scale_shift;
     return mtn_wgrad_run(p, dtype, (hipStream_t)stream);
 }
 

@@ -391,20 +391,6 @@ void igemm_kernel(IgemmArgs p) {
                        reinterpret_cast<char*>(sWin + (cs * WR8 + pr * 8) * BK));
         }
     };
-    // consumer-side BatchNorm apply (IgemmArgs::a_ss): every lane transforms the window pieces its own DMA instructions
-    // wrote -- after they have landed, before the barrier that publishes the window.  Rows outside the gather source
-    // (zero-filled) stay zero; rows of a neighbouring image row / image are real pixels that only padding taps would
-    // read, and those read the zero row instead.
-    auto bn_window = [&](int slab) {
-        const int ppc = WR8 >> 3;
-        for (int q = wid; q < CS * ppc; q += NT / 64) {
-            const int cs = q / ppc, pr = q - cs * ppc;
-            const int g = m0 - win_halo + pr * 8 + (lane >> 3);
-            if (g >= 0 && g < win_total)
-                bn_silu_piece<T>(reinterpret_cast<char*>(sWin + (cs * WR8 + pr * 8) * BK), lane, (lane & 7) ^ (lane >> 3),
-                                 (slab * CS + cs) * BK, p.a_ss, p.Cin);
-        }
-    };
     // W tile of window-mode K step kk of slab `slab` (order: tap outer, resident channel slab inner)
     auto dma_w = [&](int slab, int kk, int stage) {
         const int tap = kk / CS, cs = kk - tap * CS;
@@ -513,7 +499,6 @@ void igemm_kernel(IgemmArgs p) {
         for (; pass < passes; ++pass) {
             if (pass) __syncthreads();                     // every wave is done with the previous pass's window
             dma_window(pass);
-            if (p.a_ss) { wait_own_dma(); bn_window(pass); }
             __syncthreads();
             MTN_UNROLL for (int d = 0; d + 1 < D; ++d) load_w(d, d);
             for (int kk = 0; kk < steps; kk += D) {
@@ -531,7 +516,6 @@ void igemm_kernel(IgemmArgs p) {
             STAMP(tw0);
             dma_window(slab);
             dma_w(slab, 0, 0);
-            if (p.a_ss) { wait_own_dma(); bn_window(slab); }
             __syncthreads();
             STAMP(tw1);
 #ifdef MTN_STAMPS
@@ -1093,13 +1077,6 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
                      p.lda % 32 == 0 && p.ldc % 32 == 0 && (!p.res || p.ldr % 32 == 0) && (!p.aux_out || p.ld_aux % 32 == 0) &&
                      (!p.bn_y || p.bn_ldy % 32 == 0) && (!p.bn_res || p.bn_ldr % 32 == 0)),
                 "igemm: split storage (MTN_DTYPE_F32X3) needs 16-byte aligned operands and row pitches that are multiples of 32");
-    if (p.a_ss) {
-        const int fam = mtn_igemm_family(p, dtype);
-        MTN_REQUIRE(fam == MTN_KERNEL_IGEMM_WINDOW || fam == MTN_KERNEL_IGEMM_IMAGE,
-                    "igemm: the consumer-side BatchNorm apply exists for the window / image-tile kernels only (this shape runs kernel "
-                    "family %d: ask mtn_conv_kernel_family first)", fam);
-        MTN_REQUIRE((uintptr_t)p.a_ss % 16 == 0 && p.Cin % 8 == 0, "igemm: input scale / shift must be 16-byte aligned");
-    }
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
     if (mtn_pw_ok(p, dtype)) return mtn_pw_run(p, dtype, stream);             // short-K pointwise products: pw.hip
     if (mtn_win3_ok(p, dtype)) return mtn_win3_run(p, dtype, stream);         // 64 -> 64 channel 3x3 stride-1 layers: win3.hip

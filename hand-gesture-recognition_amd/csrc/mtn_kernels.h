@@ -38,8 +38,6 @@ struct IgemmArgs {
     const float* bn_ss;   // [2][N] scale, shift
     const float* bn_mr;   // [2][N] mean, rstd
     int bn_act;
-    const float* a_ss;    // [2][Cin] scale, shift, or null.  Not null: A is the RAW output of a Conv unit and the kernel applies
-                          // SiLU(a * scale + shift) to it in LDS (consumer-side BatchNorm apply; window / image-tile modes only)
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     int win_cs;           // filled at launch (window mode): resident 128-byte channel slabs of the activation window
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode
@@ -68,8 +66,6 @@ void mtn_win3_set(int on);
 struct WgradArgs {
     const void* dY; int lddy;     // [M][lddy] output-pixel gradients
     const void* X; int ldx;       // NHWC input of the forward conv
-    const float* x_ss;            // [2][Cin] scale, shift or null.  Not null: X is the RAW output of the Conv unit before this one and
-                                  // the kernel applies SiLU(x * scale + shift) in LDS (consumer-side BatchNorm apply; wgrad3_kernel only)
     float* partial;               // [splits][N][K] f32 workspace
     float* dW;                    // [N][Cin][KH][KW] f32 (reference OIHW layout)
     int B, H, W, Cin, OH, OW, KH, KW, stride, pad;

@@ -532,56 +532,6 @@ __device__ __forceinline__ void bn_dz_math(const float* g, float* v, const float
     }
 }
 
-// Consumer-side BatchNorm apply: the producing Conv unit stored its RAW output and the kernel that consumes
-// it as an operand tile applies SiLU(x * scale + shift) once, in LDS, after the tile has landed -- the bn_act_fwd pass
-// and the activated copy of the tensor do not exist.  One call = the 16-byte piece a lane's own LDS-DMA instruction
-// wrote: `block` is that instruction's 1 KiB block (8 rows of one 128-byte K step), the lane's piece sits at block +
-// 16 * lane and holds logical chunk L = (lane & 7) ^ (row & 7) of its row (the XOR swizzle of the operand tiles);
-// ss = [2][C] scale, shift of the producing unit, cb = first channel of the K step.  The arithmetic is bn_act_fwd_kernel's
-// (bn.hip), so a bf16 / f32 operand is bit-identical to the stored activation it replaces.  Split storage: a row is
-// [32 hi][32 lo]; the lane holding the hi piece of 8 channels (L < 4) joins it with the lo piece of the same wave
-// instruction (lane ^ 4), transforms and writes both halves back; the lo lane does nothing.
-// bn_silu_lds<T>(q, ss, C, c): the 16 / sizeof(T) channels c.. held in the 16 bytes at q (bf16 / f32).
-// bn_silu_lds_x3(qh, ql, ss, C, c): split storage -- the hi and the lo piece of the 8 channels c.. (two LDS locations of one
-// wave instruction: the lane that holds the hi piece transforms both, the lo lane does nothing).
-template <class T> __device__ __forceinline__ void bn_silu_lds(chunk16* q, const float* __restrict__ ss, int C, int c) {
-    constexpr int V = 16 / (int)sizeof(T);
-    float v[V];
-    unpack<T>(*q, v);
-    MTN_UNROLL for (int e = 0; e < V; ++e) v[e] = v[e] * ss[c + e] + ss[C + c + e];
-    MTN_UNROLL for (int e = 0; e < V; ++e) v[e] = siluf_(v[e]);
-    *q = pack<T>(v);
-}
-__device__ __forceinline__ void bn_silu_lds_x3(chunk16* qh, chunk16* ql, const float* __restrict__ ss, int C, int c) {
-    float v[8];
-    x3_join8(*qh, *ql, v);
-    MTN_UNROLL for (int e = 0; e < 8; ++e) v[e] = v[e] * ss[c + e] + ss[C + c + e];
-    MTN_UNROLL for (int e = 0; e < 8; ++e) v[e] = siluf_(v[e]);
-    chunk16 h, l;
-    x3_split8(v, h, l);
-    *qh = h;
-    *ql = l;
-}
-// igemm operand tiles: `block` = a DMA instruction's 1 KiB block (8 rows of one 128-byte K step), the lane's piece at block +
-// 16 * lane holds logical chunk L = (lane & 7) ^ (row & 7) of its row; cb = first channel of the K step (split storage: a
-// row is one 32-channel block [32 hi][32 lo], hi chunk L < 4 pairs with lo chunk L + 4 = lane ^ 4)
-template <class T> __device__ __forceinline__ void bn_silu_piece(char* block, int lane, int L, int cb, const float* __restrict__ ss, int C) {
-    bn_silu_lds<T>(reinterpret_cast<chunk16*>(block + 16 * lane), ss, C, cb + L * (16 / (int)sizeof(T)));
-}
-template <> __device__ __forceinline__ void bn_silu_piece<f32x3_t>(char* block, int lane, int L, int cb, const float* __restrict__ ss, int C) {
-    if (L < 4) bn_silu_lds_x3(reinterpret_cast<chunk16*>(block + 16 * lane), reinterpret_cast<chunk16*>(block + 16 * (lane ^ 4)), ss, C, cb + L * 8);
-}
-// (own LDS-DMA pieces have landed: what a lane must wait for before it touches them, ahead of the workgroup barrier)
-// (workgroup-uniform call sites only.  CPU executor: lanes are fibers that run one after the other up to a barrier, so "the
-//  other lane of my wave instruction has written its piece" -- a given on the GPU -- needs a barrier there.)
-__device__ __forceinline__ void wait_own_dma() {
-#ifdef MTN_EMU
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
     MTN_UNROLL for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;

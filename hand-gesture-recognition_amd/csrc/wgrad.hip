@@ -705,27 +705,6 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
         }
     };
 
-    // consumer-side BatchNorm apply (WgradArgs::x_ss): a lane transforms the window pieces its own DMA instructions wrote, once
-    // they have landed and before the barrier that publishes the stage; zero slots (padding, beyond the tensor) stay zero
-    auto bn_pieces = [&](unsigned s0, T* stage) {
-        char* base = reinterpret_cast<char*>(stage);
-        for (int q = PY + wid; q < PT; q += NW) {
-            const int row = (q - PY) * RPB + prow;
-            const int Lc = SW::fetch_chunk(row, pslot);
-            if (src(s0 - HALO + row, p.ldx, c0, Lc) == 0xFFFFFFF0u) continue;
-            chunk16* own = reinterpret_cast<chunk16*>(base + q * 1024 + 16 * lane);
-            if constexpr (std::is_same<T, f32x3_t>::value) {
-                // a 64-channel row = two blocks [32 hi][32 lo]: chunk Lc = (32-byte unit Lc >> 1, half Lc & 1); units 0, 1 of a
-                // block hold hi, units 2, 3 lo; the lo partner of a hi chunk is chunk Lc ^ 4 = lane ^ 4 of the same instruction
-                const int u = Lc >> 1;
-                if (u & 2) continue;
-                bn_silu_lds_x3(own, reinterpret_cast<chunk16*>(base + q * 1024 + 16 * (lane ^ 4)), p.x_ss, p.Cin,
-                               c0 + (u >> 2) * 32 + (u & 1) * 16 + (Lc & 1) * 8);
-            } else {
-                bn_silu_lds<T>(own, p.x_ss, p.Cin, c0 + Lc * VEC);
-            }
-        }
-    };
     // accumulators: [tap][n fragment of this wave's half]
     f32x4_t acc[9][2];
     MTN_UNROLL for (int t = 0; t < 9; ++t) { acc[t][0] = zero4(); acc[t][1] = zero4(); }
@@ -842,12 +821,10 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
                 }
             }
         }
-        if (p.x_ss && st + 1 < steps) { wait_own_dma(); bn_pieces(s_begin + (unsigned)(st + 1) * KS, wr); }
         __syncthreads();                                          // own DMA landed (vmcnt 0) + everyone is done with `rd`
     };
     if (steps > 0)
         for (int q = wid; q < PT; q += NW) dma_piece(q, s_begin, sStage0);
-    if (p.x_ss && steps > 0) { wait_own_dma(); bn_pieces(s_begin, sStage0); }
     __syncthreads();
     for (int st = 0; st < steps; st += 2) {
         step(st, sStage0, sStage1);

@@ -67,10 +67,6 @@ class Engine:
         # LayerNorm / bias gradients of the ViT are leaves: their partial-sum slabs are folded by ONE grouped call at the end
         # of the bucket instead of two launches per slab (MTN_DEFER_LEAF_SUMS=0: fold each one where it is produced)
         self.defer_leaf_sums = os.environ.get("MTN_DEFER_LEAF_SUMS", "1") != "0"
-        # consumer-side BatchNorm apply for the `t` tensor of a residual block (c1 -> c2, nothing else reads it): c1
-        # stores only its raw output, c2's forward (window / image-tile kernel) and c2's weight gradient (window kernel) apply
-        # SiLU(raw * scale + shift) to their operand in LDS -- no bn_act_fwd launch, no activated copy (MTN_FUSE_T=0: off)
-        self.fuse_t = os.environ.get("MTN_FUSE_T", "1") != "0"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -107,12 +103,6 @@ class Engine:
                               for seq in (blk.cv2, blk.cv3)]
             st["cv4"] = unit(blk.cv4, h, w)
             st["down"] = unit(down, h, w) if down is not None else None
-            for br in st["branches"]:
-                for rb in br:
-                    c2 = rb["c2"]
-                    geom = (self.dt, B, c2.hin, c2.win, c2.cin, c2.cout, c2.k, c2.s)
-                    rb["fuse_t"] = bool(self.fuse_t and c2.k == 3 and c2.s == 1 and self.o.conv_fwd_bn_in_ok(*geom)
-                                        and self.o.conv_wgrad_family(*geom) == 1)
             st["cv1"].tag, st["cv4"].tag = f"s{si + 1}.cv1", f"s{si + 1}.cv4"
             if down is not None:
                 st["down"].tag = f"s{si + 1}.down"
@@ -331,19 +321,17 @@ class Engine:
         bn = u.mod.bn
         self.o.bn_finalize(u.stats, u.tiles, u.M, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                         bn.num_batches_tracked, u.ss, u.mr, bn.momentum, bn.eps)
-        if out is None or u.tag in self.ablate_fwd:
+        if u.tag in self.ablate_fwd:
             return
         self.o.bn_act_fwd(u.raw, u.ss, out, _ACT[u.act or res is not None], res)
 
-    def _conv(self, u, x, out, training, res=None, in_ss=None):
-        """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87).  Training only: ``in_ss`` -- x is the raw output of the
-        unit before and the kernel applies that unit's BatchNorm + SiLU itself; ``out`` None -- leave only u.raw and u.ss
-        (the consumer applies them)."""
+    def _conv(self, u, x, out, training, res=None):
+        """out = act(bn(conv(x)) [+ res])   (model/gelan.py:56, 78-87)"""
         if not training:
             # eval(): BatchNorm folded into the weights (pack_weights(folded=True)) and an epilogue bias: one launch
             self.o.conv_bias_act_fwd(x, u.wf, u.ss[1], out, _ACT[u.act or res is not None], u.k, u.s, res=res)
             return
-        self.o.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles, in_ss=in_ss)
+        self.o.conv_fwd(x, u.wf, u.raw, u.stats, u.k, u.s, stats_tiles=u.tiles)
         self._bn_fwd(u, out, res)
 
     def _dgrad(self, u, dy, g_in, g_in_res=None, nxt=None):
@@ -360,17 +348,17 @@ class Engine:
                        bn=(n.raw, nres, n.ss, n.mr, _ACT[n.act or nres is not None], self.bn_part, u.dgrad_tiles))
         n.pre_rows = u.dgrad_tiles
 
-    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True, nxt=None, x_ss=None):
+    def _conv_bwd(self, u, g_out, x, g_in, res=None, dres=None, g_in_res=None, dres_accumulate=True, nxt=None):
         """Backward of _conv: BN+act backward -> wgrad -> dgrad (g_in = dgrad [+ g_in_res]).
         ``dres`` receives the gradient of the residual operand, added to its old contents unless
-        ``dres_accumulate`` is False.  ``nxt``: see _dgrad.  ``x_ss``: x is a raw output, see _conv(in_ss=...)."""
+        ``dres_accumulate`` is False.  ``nxt``: see _dgrad."""
         bn, dy = u.mod.bn, self._dy(u)
         rows, u.pre_rows = u.pre_rows, 0
         if u.tag not in self.ablate_bwd:
             self.o.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
                               dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
                               partial_rows=rows)
-        self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s, in_ss=x_ss)
+        self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
         if g_in is not None:
             self._dgrad(u, dy, g_in, g_in_res, nxt)
 
@@ -411,12 +399,8 @@ class Engine:
                 xin = cat[..., h2 * (j + 1):h2 * (j + 2)]
                 for i, rb in enumerate(br):
                     out = cat[..., h2 * (j + 2):h2 * (j + 3)] if i + 1 == len(br) else rb["o"]
-                    if training and rb["fuse_t"]:
-                        self._conv(rb["c1"], xin, None, training)
-                        self._conv(rb["c2"], rb["c1"].raw, out, training, res=xin, in_ss=rb["c1"].ss)
-                    else:
-                        self._conv(rb["c1"], xin, rb["t"], training)
-                        self._conv(rb["c2"], rb["t"], out, training, res=xin)
+                    self._conv(rb["c1"], xin, rb["t"], training)
+                    self._conv(rb["c2"], rb["t"], out, training, res=xin)
                     xin = out
             self._conv(st["cv4"], cat, st["out"], training)
             cur = st["out"]
@@ -514,9 +498,8 @@ class Engine:
                     first = i == 0
                     xin = cat[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["o"]
                     g_xin = gc[..., h2 * (j + 1):h2 * (j + 2)] if first else br[i - 1]["g_o"]
-                    fz = rb["fuse_t"]
-                    self._conv_bwd(rb["c2"], g_out, rb["c1"].raw if fz else rb["t"], st["g_t"], res=xin, dres=g_xin,
-                                   dres_accumulate=first, nxt=(rb["c1"], None), x_ss=rb["c1"].ss if fz else None)
+                    self._conv_bwd(rb["c2"], g_out, rb["t"], st["g_t"], res=xin, dres=g_xin, dres_accumulate=first,
+                                   nxt=(rb["c1"], None))
                     # g_xin is complete after c1's data gradient, except the y1 slice of the concat (branch 0, first
                     # block), which is only half of cv1's output gradient.  Its consumer: the previous block's c2,
                     # or -- for the y2 slice (branch 1, first block) -- the last block of branch 0

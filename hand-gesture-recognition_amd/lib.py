@@ -27,9 +27,6 @@ _PROTOS = {
     "mtn_linear_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_wgrad_workspace_bytes": [_i] * 8,
     "mtn_conv_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "mtn_conv_wgrad_family": [_i] * 8,
-    "mtn_conv_wgrad_bn_in": [_vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "mtn_conv_fwd_bn_in": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_linear_wgrad_workspace_bytes": [_i] * 4,
     "mtn_linear_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mtn_conv1_stats_tiles": [_i, _i, _i],
@@ -88,7 +85,7 @@ _PROTOS = {
     "mtn_debug_read": [_i, _vp, _sz],
 }
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz, "mtn_pose_slab_floats": _sz}
-_STATUS_FREE = {"mtn_abi_version", "mtn_conv_wgrad_family", "mtn_has_experiments", "mtn_debug_key_is_experiment", "mtn_conv_kernel_family", "mtn_colsum_rows_per_block", "mtn_colsum_direct_rows", "mtn_rowslab_producer_rows", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
+_STATUS_FREE = {"mtn_abi_version", "mtn_has_experiments", "mtn_debug_key_is_experiment", "mtn_conv_kernel_family", "mtn_colsum_rows_per_block", "mtn_colsum_direct_rows", "mtn_rowslab_producer_rows", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
                 "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",

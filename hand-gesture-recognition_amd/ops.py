@@ -107,11 +107,9 @@ def conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
     return lib.call("mtn_conv_fwd_stats_tiles", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
-def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None, mode=None, in_ss=None):
+def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None, mode=None):
     """x [B,H,W,Cin] -> y [B,OH,OW,Cout] raw conv output; stats [>=tiles,2,Cout] f32 or None
-    (tiles = conv_fwd_stats_tiles(...): the slab is allocated with slab_rows(tiles) rows).  ``in_ss`` (f32 [2, Cin]): x is
-    the RAW output of the Conv unit before this one and the kernel applies SiLU(x * scale + shift) to it on the way in
-    (only where conv_fwd_bn_in_ok(...))."""
+    (tiles = conv_fwd_stats_tiles(...): the slab is allocated with slab_rows(tiles) rows)."""
     B, H, W, Cin = x.shape
     Cout = y.shape[-1]
     xp, ldx = _rows(x)
@@ -123,26 +121,8 @@ def conv_fwd(x, w, y, stats, ksize, stride, stats_tiles=None, mode=None, in_ss=N
         tiles = conv_fwd_stats_tiles(x.dtype, B, H, W, Cin, Cout, ksize, stride, mode=mode) if stats_tiles is None else int(stats_tiles)
         if stats.dtype != torch.float32 or stats.numel() < tiles * 2 * Cout:
             raise ValueError(f"conv_fwd: stats slab too small for {tiles} row tiles")
-    if in_ss is not None:
-        if in_ss.dtype != torch.float32 or in_ss.numel() != 2 * Cin or not in_ss.is_contiguous():
-            raise ValueError("conv_fwd: in_ss must be a contiguous f32 [2, Cin]")
-        lib.call("mtn_conv_fwd_bn_in", xp, ldx, in_ss.data_ptr(), w.data_ptr(), yp, ldy, _p(stats), tiles, dtype_code(x, mode),
-                 B, H, W, Cin, Cout, ksize, stride, _stream(x))
-        return
     lib.call("mtn_conv_fwd", xp, ldx, w.data_ptr(), yp, ldy, _p(stats), tiles, dtype_code(x, mode),
              B, H, W, Cin, Cout, ksize, stride, _stream(x))
-
-
-def conv_fwd_bn_in_ok(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
-    """True where conv_fwd(in_ss=...) is served: the window / image-tile kernels (include/mtn.h: mtn_conv_fwd_bn_in)."""
-    return conv_kernel_family(dtype, False, B, H, W, Cin, Cout, ksize, stride, mode=mode) in (1, 2)
-
-
-def conv_wgrad_family(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
-    fam = lib.call("mtn_conv_wgrad_family", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
-    if fam < 0:
-        raise RuntimeError(f"mtn_conv_wgrad_family: {lib.get().mtn_last_error().decode()}")
-    return fam
 
 
 def conv_bias_act_fwd(x, w, bias, y, act, ksize, stride, res=None, mode=None):
@@ -226,20 +206,13 @@ def conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride, mode=No
     return lib.call("mtn_conv_wgrad_workspace_bytes", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
-def conv_wgrad(x, dy, dw, workspace, ksize, stride, mode=None, in_ss=None):
-    """x [B,H,W,Cin], dy [B,OH,OW,Cout] -> dw f32 [Cout,Cin,k,k] (overwritten).  ``in_ss``: as in conv_fwd (only where
-    conv_wgrad_family(...) == 1)."""
+def conv_wgrad(x, dy, dw, workspace, ksize, stride, mode=None):
+    """x [B,H,W,Cin], dy [B,OH,OW,Cout] -> dw f32 [Cout,Cin,k,k] (overwritten)."""
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
     xp, ldx = _rows(x)
     dyp, lddy = _rows(dy)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
-    if in_ss is not None:
-        if in_ss.dtype != torch.float32 or in_ss.numel() != 2 * Cin or not in_ss.is_contiguous():
-            raise ValueError("conv_wgrad: in_ss must be a contiguous f32 [2, Cin]")
-        lib.call("mtn_conv_wgrad_bn_in", xp, ldx, in_ss.data_ptr(), dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
-                 workspace.numel() * workspace.element_size(), dtype_code(x, mode), B, H, W, Cin, Cout, ksize, stride, _stream(x))
-        return
     lib.call("mtn_conv_wgrad", xp, ldx, dyp, lddy, dw.data_ptr(), workspace.data_ptr(),
              workspace.numel() * workspace.element_size(), dtype_code(x, mode), B, H, W, Cin, Cout,
              ksize, stride, _stream(x))

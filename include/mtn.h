@@ -67,14 +67,6 @@ int mtn_conv_stats_tiles(int M, int Cout, int K);
 int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float* stats, int stats_tiles,
                  int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                  void* stream);
-/* (ABI 6) the same convolution when x is the RAW (pre-BatchNorm) output of the Conv unit before it and nothing else reads
- * that unit's activated output: the kernel applies SiLU(x * scale + shift) to its activation operand itself, in LDS, once
- * per tile (in_scale_shift = [2][Cin] from mtn_bn_finalize) -- the mtn_bn_act_fwd pass and the activated tensor do not
- * exist (reference: act(bn(conv(x))) feeding the next conv, model/gelan.py:56,78-87).  Served by the window /
- * image-tile kernels only: call it where mtn_conv_kernel_family says MTN_KERNEL_IGEMM_WINDOW or _IMAGE (refused
- * elsewhere).  bf16 / f32 operands are bit-identical to the stored activation they replace. */
-int mtn_conv_fwd_bn_in(const void* x, int ldx, const float* in_scale_shift, const void* w, void* y, int ldy, float* stats,
-                       int stats_tiles, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
 /* Inference form of a Conv unit with its BatchNorm folded away (model/gelan.py:56, 78-87 in eval()):
  * y = act(conv(x) + bias [+ res]), act in {NONE, SILU}; w = the folded weights (mtn_pack_weights with a
@@ -155,14 +147,6 @@ size_t mtn_conv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int Cin, i
 int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                    size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout, int ksize,
                    int stride, void* stream);
-/* (ABI 6) which weight-gradient kernel serves a conv shape: 0 = one tap per tile (wgrad_dma2_kernel), 1 = the 3x3 stride-1
- * window kernel (wgrad3_kernel), 2 = kernel-row tiles (wgrad_row3_kernel); -1 on bad arguments. */
-int mtn_conv_wgrad_family(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
-/* (ABI 6) mtn_conv_wgrad when x is the RAW output of the Conv unit before this one (see mtn_conv_fwd_bn_in): the window
- * kernel applies SiLU(x * scale + shift) to its input window in LDS.  Only where mtn_conv_wgrad_family says 1. */
-int mtn_conv_wgrad_bn_in(const void* x, int ldx, const float* in_scale_shift, const void* dy, int lddy, float* dw,
-                         void* workspace, size_t ws_bytes, int dtype, int B, int H, int W, int Cin, int Cout,
-                         int ksize, int stride, void* stream);
 size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
 int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                      size_t ws_bytes, int dtype, int M, int N, int K, void* stream);

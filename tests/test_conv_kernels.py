@@ -793,94 +793,3 @@ def test_conv3x3_persistent_kernel(be, win3_forced, cfg):
     assert torch.equal(dxr.view(torch.int16), dxr0.view(torch.int16))
     scale = float(pt0.abs().max()) + 1e-6
     assert float((pt - pt0).abs().max()) < 2e-4 * scale, (pt, pt0)
-
-
-# ---- consumer-side BatchNorm apply (mtn_conv_fwd_bn_in / mtn_conv_wgrad_bn_in: SURVEY K4, the `t` tensor of a residual block) ----
-def _bn_in_operands(be, dtype, B, H, W, Cin, seed):
-    """raw output of the 'previous' unit, its scale / shift, and the activated tensor the unfused path would store"""
-    d = be.device
-    raw = A(_rand((B, H, W, Cin), dtype, seed) * 1.5 + 0.25).to(d)
-    g = torch.Generator().manual_seed(seed + 1)
-    ss = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).contiguous().to(d)
-    act = torch.empty_like(raw)
-    ops.bn_act_fwd(raw, ss, act, ops.ACT_SILU)
-    return raw, ss, act
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [
-    # B, H, W, Cin, Cout  (3x3 stride 1, window mode: 64-wide outputs or the 64 x 128 tile)
-    (2, 8, 8, 64, 64),           # one resident slab (bf16), two tiles
-    (1, 12, 12, 64, 64),         # a 12-column map: neighbouring image rows inside the halo
-    (3, 5, 7, 128, 64),          # two slabs, images shorter than a tile: windows span three images
-    (2, 6, 6, 64, 128),          # 128-wide output
-])
-def test_conv_fwd_applies_the_input_batchnorm(be, dtype, cfg):
-    """conv_fwd(raw, in_ss) == conv_fwd(bn_act_fwd(raw)), bit for bit (same arithmetic on the same values, applied in LDS),
-    output and statistics; a shape the window kernels do not serve is refused."""
-    B, H, W, Cin, Cout = cfg
-    d = be.device
-    dbg(9, 150)                    # (every stride-1 3x3 shape through the window path, as the model's stage-1 layers are)
-    try:
-        assert ops.conv_fwd_bn_in_ok(dtype, B, H, W, Cin, Cout, 3, 1)
-        raw, ss, act = _bn_in_operands(be, dtype, B, H, W, Cin, 81)
-        w = pack_krsc(_rand((Cout, Cin, 3, 3), torch.float32, 83) / (Cin * 9) ** 0.5, dtype).to(d)
-        tiles = ops.conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, 3, 1)
-        outs = []
-        for x, in_ss in ((act, None), (raw, ss)):
-            y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=d)
-            stats = torch.full((tiles, 2, Cout), float("nan"), device=d)
-            ops.conv_fwd(x, w, y, stats, 3, 1, stats_tiles=tiles, in_ss=in_ss)
-            be.sync()
-            outs.append((y.cpu(), stats.cpu()))
-        assert torch.equal(outs[0][0].view(torch.uint8), outs[1][0].view(torch.uint8)) and torch.equal(outs[0][1], outs[1][1])
-        assert torch.isfinite(Fl(outs[1][0])).all()
-        with pytest.raises(RuntimeError, match="window / image-tile"):           # a 1x1 layer is not a window shape
-            y2 = torch.empty((B, H, W, Cout), dtype=dtype, device=d)
-            w2 = pack_krsc(_rand((Cout, Cin, 1, 1), torch.float32, 84), dtype).to(d)
-            ops.conv_fwd(raw, w2, y2, None, 1, 1, in_ss=ss)
-    finally:
-        dbg(9, 0)
-
-
-@pytest.mark.parametrize("dtype", [pytest.param(torch.bfloat16, id="bf16"), pytest.param(torch.float32, id="x3", marks=pytest.mark.x3)])
-@pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 256), (1, 5, 7, 256, 256)])
-def test_conv_image_tile_applies_the_input_batchnorm(be, image_tiles, dtype, cfg):
-    """the same through the image-tile kernel (stage-3 3x3 layers; split storage: two passes over the window at 256 channels)"""
-    B, H, W, Cin, Cout = cfg
-    d = be.device
-    assert ops.conv_kernel_family(dtype, False, B, H, W, Cin, Cout, 3, 1) == 2
-    raw, ss, act = _bn_in_operands(be, dtype, B, H, W, Cin, 91)
-    w = pack_krsc(_rand((Cout, Cin, 3, 3), torch.float32, 93) / (Cin * 9) ** 0.5, dtype).to(d)
-    tiles = ops.conv_fwd_stats_tiles(dtype, B, H, W, Cin, Cout, 3, 1)
-    outs = []
-    for x, in_ss in ((act, None), (raw, ss)):
-        y = torch.full((B, H, W, Cout), float("nan"), dtype=dtype, device=d)
-        stats = torch.full((tiles, 2, Cout), float("nan"), device=d)
-        ops.conv_fwd(x, w, y, stats, 3, 1, stats_tiles=tiles, in_ss=in_ss)
-        be.sync()
-        outs.append((y.cpu(), stats.cpu()))
-    assert torch.equal(outs[0][0].view(torch.uint8), outs[1][0].view(torch.uint8)) and torch.equal(outs[0][1], outs[1][1])
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 6, 6, 64, 64), (1, 12, 12, 64, 128), (3, 5, 7, 128, 64), (2, 9, 6, 256, 64)])
-def test_conv_wgrad_applies_the_input_batchnorm(be, dtype, cfg):
-    """conv_wgrad(raw, dy, in_ss) == conv_wgrad(bn_act_fwd(raw), dy) bit for bit through the 3x3 stride-1 window kernel (zero
-    slots of the padded slot axis stay zero); other weight-gradient kernels refuse."""
-    B, H, W, Cin, Cout = cfg
-    d = be.device
-    assert ops.conv_wgrad_family(dtype, B, H, W, Cin, Cout, 3, 1) == 1
-    raw, ss, act = _bn_in_operands(be, dtype, B, H, W, Cin, 101)
-    dy = A(_rand((B, H, W, Cout), dtype, 103)).to(d)
-    ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 3, 1) // 4, dtype=torch.float32, device=d)
-    got = []
-    for x, in_ss in ((act, None), (raw, ss)):
-        dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=d)
-        ops.conv_wgrad(x, dy, dw, ws, 3, 1, in_ss=in_ss)
-        be.sync()
-        got.append(dw.cpu())
-    assert torch.equal(got[0], got[1]) and torch.isfinite(got[1]).all()
-    with pytest.raises(RuntimeError, match="window kernel only"):
-        ws1 = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 1, 1) // 4, dtype=torch.float32, device=d)
-        ops.conv_wgrad(raw, dy, torch.empty((Cout, Cin, 1, 1), device=d), ws1, 1, 1, in_ss=ss)
