@@ -380,8 +380,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
                     const f32x4_t s = mma32(kf, qf, zero4());
                     const f32x4_t dp = mma32(vf, dof, zero4());
                     MTN_UNROLL for (int r = 0; r < 4; ++r) {
+                        // (the softmax scale is applied once to the 8 accumulated values of the lane's query below, not to every
+                        //  score: the kernel is VALU-bound -- fma / exp2 / sub / mul per score instead of five)
                         const float p = exp2f_(fmaf(s[r], c2, -lq2));
-                        ds[u][r] = p * (dp[r] - dl) * scale;
+                        ds[u][r] = p * (dp[r] - dl);
                     }
                     if (FULL ? (kt >= MAXT - 2) : (kt * 16 + 16 > N)) {   // tiles that can hold padded keys: exp(0 - lse) may overflow
                         MTN_UNROLL for (int r = 0; r < 4; ++r)
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
             }
             if (FULL) MTN_SCHED_FENCE();
         }
+        MTN_UNROLL for (int r = 0; r < 4; ++r) { d0[r] *= scale; d1[r] *= scale; }
         if (qok) {
             T* dp = dqkv + (row0 + q) * ld + h * HD;
             st4v<T>(dp, 4 * g, d0);
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
     stage_heads<T>(sQ, qkv, ld, h * HD, sD, dout, ldo, h * HD, row0, N, NP);
     if (kStageRows)
         for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-            sL[i] = i < N ? lse[(long)bh * N + i] : 0.f;
+            sL[i] = i < N ? lse[(long)bh * N + i] * 1.4426950408889634f : 0.f;      // (in log2 units: one multiply per row, not per score)
             sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
         }
     __syncthreads();
@@ -460,11 +463,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
                 //  dV = P^T dO and dK = dS^T Q; padded key lanes compute columns that are never stored)
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
                     const int q = qb + 4 * g + r;
-                    const float lq = kStageRows ? sL[q] : (q < N ? lse[(long)bh * N + q] : 0.f);
+                    const float lq = kStageRows ? sL[q] : (q < N ? lse[(long)bh * N + q] * 1.4426950408889634f : 0.f);
                     const float dq = kStageRows ? sDl[q] : (q < N ? delta[(long)bh * N + q] : 0.f);
-                    const float pv = exp2f_(fmaf(s[r], c2, -lq * 1.4426950408889634f));
+                    const float pv = exp2f_(fmaf(s[r], c2, -lq));
                     p[hf][r] = pv;
-                    ds[hf][r] = pv * (dp[r] - dq) * scale;
+                    ds[hf][r] = pv * (dp[r] - dq);           // (scale: once on dK below)
                 }
             }
             dv0 = acc_mma(sD + qp * 32 * PITCH, 0, PITCH, p[0], p[1], dv0, lane);          // dV^T += dO^T P
@@ -472,6 +475,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
             dk0 = acc_mma(sQ + qp * 32 * PITCH, 0, PITCH, ds[0], ds[1], dk0, lane);        // dK^T += Q^T dS
             dk1 = acc_mma(sQ + qp * 32 * PITCH, 16, PITCH, ds[0], ds[1], dk1, lane);
         }
+        MTN_UNROLL for (int r = 0; r < 4; ++r) { dk0[r] *= scale; dk1[r] *= scale; }
         if (kok) {
             T* dkp = dqkv + (row0 + key) * ld + H * HD + h * HD;
             T* dvp = dqkv + (row0 + key) * ld + 2 * H * HD + h * HD;

@@ -865,7 +865,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
     int win_cs = 0;
     if (STAGES == 5 || STAGES == 6) {
-        win_cs = STAGES == 6 ? igemm_image_tile_cs(p, (int)sizeof(T)) : igemm_window_cs(p, (int)sizeof(T), BM, BN);
+        win_cs = STAGES == 6 ? igemm_image_tile_cs(p, (int)sizeof(T)) : (BM * BN == 128 * 128 ? 2 : igemm_window_cs(p, (int)sizeof(T), BM, BN));
         const size_t win = igemm_window_bytes(p, BM, STAGES == 6 ? 0 : BN, win_cs);
         const size_t rest = lds_c > lds_r ? lds_c : lds_r;
         lds = win > rest ? win : rest;
@@ -944,6 +944,11 @@ static int igemm_config(int M, int N, int K) {
     return 3;
 }
 
+// bf16, 128x128 tile: window mode with both 64-channel slabs of a 128-channel layer resident, while two workgroups still fit a CU
+static bool igemm_window128_ok(const IgemmArgs& p) {
+    return g_igemm_stages == 5 && igemm_window_shape(p) && p.Cin == 128 && igemm_window_bytes(p, 128, 128, 2) <= 79 * 1024;
+}
+
 template <class T>
 int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     if constexpr (sizeof(T) == 2 || std::is_same<T, f32x3_t>::value) {
@@ -970,6 +975,12 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
             return g_igemm_tile == 4 ? launch_igemm_dma2<T, 256, 128, 4, 2, 7>(p, stream) : launch_igemm_dma2<T, 128, 128, 4, 2, 7>(p, stream);
     }
 #endif
+    // the window mode on the 8-wave 128x128 tile (round 5): the stage-2 3x3 layers -- 128 channels at 24x24: 45 KB of window + two
+    // 16 KB weight tiles = 78 KB, two workgroups per CU as before.  Round 2 measured the window at 128x128 with FOUR waves (+4 %),
+    // the 8-wave tile came later (+5..9 %); together: forward 65.2 -> 64.0 us, step -0.035 ms (profiles/r05_window128_ab.txt)
+    if constexpr (sizeof(T) == 2) {
+        if (cfg == 0 && igemm_window128_ok(p)) return launch_igemm<T, 128, 128, 4, 2, 5, 2>(p, stream);
+    }
     if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages >= 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
 #ifdef MTN_EXPERIMENTS
     if (cfg == 0 && g_igemm_stages == 3) return launch_igemm<T, 128, 128, 4, 2, 3>(p, stream);
@@ -1031,8 +1042,8 @@ int mtn_igemm_family(const IgemmArgs& p, int dtype) {
     const int esz = dtype == MTN_BF16 ? 2 : 4;
     if (g_igemm_stages == 5 && !p.pm && igemm_window_shape(p)) {
         static const int bm[4] = {128, 64, 256, 128}, bn[4] = {128, 128, 64, 64};
-        const int cfg = igemm_config(p.M, p.N, p.K);      // (the 8-wave 128x128 tile has no window form: dispatch_igemm)
-        if (cfg != 0 && igemm_window_ok(p, bm[cfg], bn[cfg], esz)) return MTN_KERNEL_IGEMM_WINDOW;
+        const int cfg = igemm_config(p.M, p.N, p.K);      // (the 8-wave 128x128 tile: bf16 layers of 128 channels only, dispatch_igemm)
+        if (cfg == 0 ? (dtype == MTN_BF16 && igemm_window128_ok(p)) : igemm_window_ok(p, bm[cfg], bn[cfg], esz)) return MTN_KERNEL_IGEMM_WINDOW;
     }
     return MTN_KERNEL_IGEMM;
 }

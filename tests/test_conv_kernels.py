@@ -204,7 +204,8 @@ def test_conv_fwd_channel_slices(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 128, 3, 1), (1, 16, 16, 128, 256, 1, 1), (2, 12, 12, 64, 128, 3, 2)])
+@pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 128, 3, 1), (1, 16, 16, 128, 256, 1, 1), (2, 12, 12, 64, 128, 3, 2),
+                                 (2, 12, 12, 128, 128, 3, 1), (3, 5, 7, 128, 256, 3, 1)])      # 128 channels, 3x3 stride 1: the tile's window form (bf16)
 def test_conv_fwd_forced_128x128_tile(be, dtype, cfg):
     """the 128x128 tile (8 waves) is only chosen for M >= 8192: force it on shapes the CPU executor can run"""
     from hand_gesture_recognition_amd import lib
@@ -214,18 +215,33 @@ def test_conv_fwd_forced_128x128_tile(be, dtype, cfg):
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dtype).float(), None, s, k // 2).permute(0, 2, 3, 1)
     OH, OW = ref.shape[1:3]
     M = B * OH * OW
+    win128 = dtype == torch.bfloat16 and k == 3 and s == 1 and Cin == 128        # (round 5: this tile's window form)
+    dx = dref = None
     dbg(6, 1)
     try:
+        assert (ops.conv_kernel_family(dtype, False, B, H, W, Cin, Cout, k, s) == 1) == win128
         y = torch.full((B, OH, OW, Cout), float("nan"), dtype=dtype, device=be.device)
         stats = torch.full((ops.conv_stats_tiles(M, Cout, k * k * Cin), 2, Cout), float("nan"), device=be.device)
         ops.conv_fwd(A(x).to(be.device), pack_krsc(w, dtype).to(be.device), y, stats, k, s)
         be.sync()
+        if k == 3 and s == 1 and Cout == 128:
+            # the data gradient of a 128 -> Cin layer through the same tile (gather source = dy with 128 channels)
+            w2 = _rand((Cout, Cin, 3, 3), torch.float32, 33) / (Cin * 9) ** 0.5      # conv Cin -> Cout; dgrad: N = Cin, K = 9 Cout
+            xz = torch.zeros((B, Cin, H, W), requires_grad=True)
+            dyv = _rand((B, H, W, Cout), dtype, 34)
+            F.conv2d(xz, w2.to(dtype).float(), None, 1, 1).backward(dyv.float().permute(0, 3, 1, 2))
+            dref = xz.grad.permute(0, 2, 3, 1)
+            dx = torch.full((B, H, W, Cin), float("nan"), dtype=dtype, device=be.device)
+            ops.conv_dgrad(A(dyv).to(be.device), pack_crsk(w2, dtype).to(be.device), dx, None, 3, 1)
+            be.sync()
     finally:
         dbg(6, 0)
     assert stats.shape[0] == (M + 127) // 128
     assert rel_err(Fl(y), ref) < tol(dtype)
     yf = Fl(y).reshape(M, Cout)
     assert rel_err(stats.cpu().sum(0)[0], yf.sum(0)) < 1e-3
+    if dx is not None:
+        assert rel_err(Fl(dx), dref) < tol(dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
