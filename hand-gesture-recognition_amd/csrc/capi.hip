@@ -107,16 +107,15 @@ int mtn_conv_dgrad_bn_tiles(int dtype, int B, int H, int W, int Cin, int Cout, i
 }
 
 // BatchNorm-backward hand-over: mtn_conv_dgrad_bn leaves `tiles` rows of (sum dz, sum dz*xhat) in bn_partial and the
-// next mtn_bn_act_bwd on this thread consumes them instead of reducing (dout, y) itself.  The consumer cannot see
-// what the producer wrote, so the producer records it (per thread: the two calls are consecutive steps of one
-// backward pass) and the consumer requires its partial_rows / slab / channel count to match that record.
-struct BnHandover { const float* partial; int tiles; int C; int dtype; };
-static thread_local BnHandover g_handover = {nullptr, 0, 0, 0};
-
+// mtn_bn_act_bwd of the unit they belong to consumes them instead of reducing (dout, y) itself.  The consumer cannot see
+// what the producer wrote, so the producer describes it in a record the CALLER owns (mtn_bn_handover, include/mtn.h) and the
+// consumer requires its partial_rows / slab / channel count to match that record, then clears it: a hand-over is used once.
+// (Until ABI 5 the record was a thread-local of the library holding a device pointer between two calls; SURVEY 8b: the
+//  library retains nothing past a call.)
 int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res, int ldres,
                       const void* bn_y, int bn_ldy, const void* bn_res, int bn_ldres, const float* bn_scale_shift,
-                      const float* bn_mean_rstd, int bn_act, float* bn_partial, int bn_tiles, int dtype, int B, int H,
-                      int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+                      const float* bn_mean_rstd, int bn_act, float* bn_partial, int bn_tiles, mtn_bn_handover* record, int dtype,
+                      int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
     IgemmArgs p{};
     const int rc = conv_dgrad_args(p, "conv_dgrad_bn", B, H, W, Cin, Cout, ksize, stride);
     if (rc) return rc;
@@ -126,9 +125,10 @@ int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int ld
     p.bn_y = bn_y; p.bn_ldy = bn_ldy; p.bn_res = bn_res; p.bn_ldr = bn_ldres;
     p.bn_ss = bn_scale_shift; p.bn_mr = bn_mean_rstd; p.bn_act = bn_act;
     p.stats = bn_partial; p.stats_rows = bn_tiles;
-    g_handover = {nullptr, 0, 0, 0};
+    MTN_REQUIRE(record, "conv_dgrad_bn: null hand-over record");
+    *record = mtn_bn_handover{nullptr, 0, 0, 0};
     const int rc2 = mtn_igemm_run(p, dtype, (hipStream_t)stream);
-    if (rc2 == MTN_OK) g_handover = {bn_partial, bn_tiles, Cin, dtype};
+    if (rc2 == MTN_OK) *record = mtn_bn_handover{bn_partial, bn_tiles, Cin, dtype};
     return rc2;
 }
 
@@ -273,16 +273,18 @@ int mtn_bn_bwd_partial_rows(int M) { return mtn_reduce_rows_needed(mtn_bn_bwd_bl
 int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
                    const float* scale_shift, const float* mean_rstd, float* partial, float* coef,
                    float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
-                   const void* extra, int ldextra, int partial_rows, int dtype, int M, int C, int act, void* stream) {
+                   const void* extra, int ldextra, int partial_rows, mtn_bn_handover* record, int dtype, int M, int C, int act,
+                   void* stream) {
     BnBwdArgs a{};
     if (partial_rows > 0) {
-        const BnHandover h = g_handover;
-        g_handover = {nullptr, 0, 0, 0};                // consumed (or refused) exactly once
-        MTN_REQUIRE(h.partial != nullptr, "bn_act_bwd: partial_rows=%d but no mtn_conv_dgrad_bn launch on this thread left "
-                    "BatchNorm-backward sums (or they were already consumed)", partial_rows);
-        MTN_REQUIRE(h.partial == partial && h.tiles == partial_rows && h.C == C && h.dtype == dtype,
+        MTN_REQUIRE(record, "bn_act_bwd: partial_rows=%d needs the hand-over record mtn_conv_dgrad_bn filled", partial_rows);
+        const mtn_bn_handover h = *record;
+        *record = mtn_bn_handover{nullptr, 0, 0, 0};     // consumed (or refused) exactly once
+        MTN_REQUIRE(h.partial != nullptr, "bn_act_bwd: partial_rows=%d but no mtn_conv_dgrad_bn launch left "
+                    "BatchNorm-backward sums in this record (or they were already consumed)", partial_rows);
+        MTN_REQUIRE(h.partial == partial && h.tiles == partial_rows && h.channels == C && h.dtype == dtype,
                     "bn_act_bwd: partial_rows=%d rows of %d channels do not match what the preceding mtn_conv_dgrad_bn "
-                    "wrote (%d rows of %d channels%s)", partial_rows, C, h.tiles, h.C, h.partial == partial ? "" : ", another slab");
+                    "wrote (%d rows of %d channels%s)", partial_rows, C, h.tiles, h.channels, h.partial == partial ? "" : ", another slab");
     }
     a.partial_rows = partial_rows;
     a.dout = dout; a.lddo = lddo; a.y = y; a.ldy = ldy; a.res = res; a.ldr = ldres;

@@ -22,7 +22,7 @@ _PROTOS = {
     "mtn_conv_dgrad": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_dgrad_bn_tiles": [_i, _i, _i, _i, _i, _i, _i, _i],
     "mtn_conv_fwd_stats_tiles": [_i, _i, _i, _i, _i, _i, _i, _i],
-    "mtn_conv_dgrad_bn": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
+    "mtn_conv_dgrad_bn": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp,
                           _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_linear_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mtn_conv_wgrad_workspace_bytes": [_i] * 8,
@@ -47,7 +47,7 @@ _PROTOS = {
     "mtn_linear_gelu_bwd_tiles": [_i, _i, _i],
     "mtn_linear_gelu_bwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "mtn_bn_act_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
-                       _i, _i, _i, _i, _i, _vp],
+                       _i, _vp, _i, _i, _i, _i, _vp],
     "mtn_tokens_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_tokens_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_layernorm_fwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _f, _vp],
@@ -84,6 +84,11 @@ _PROTOS = {
     "mtn_debug_set": [_i, _i],
     "mtn_debug_read": [_i, _vp, _sz],
 }
+class BnHandover(C.Structure):
+    """include/mtn.h mtn_bn_handover: what a mtn_conv_dgrad_bn launch wrote, owned by the caller between the two calls"""
+    _fields_ = [("partial", C.c_void_p), ("tiles", C.c_int), ("channels", C.c_int), ("dtype", C.c_int)]
+
+
 _RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz, "mtn_pose_slab_floats": _sz}
 _STATUS_FREE = {"mtn_abi_version", "mtn_has_experiments", "mtn_debug_key_is_experiment", "mtn_conv_kernel_family", "mtn_colsum_rows_per_block", "mtn_colsum_direct_rows", "mtn_rowslab_producer_rows", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
                 "mtn_linear_wgrad_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",

@@ -143,6 +143,23 @@ def conv_dgrad_bn_tiles(dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
     return lib.call("mtn_conv_dgrad_bn_tiles", code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride)
 
 
+# The hand-over record between conv_dgrad(bn=...) and the bn_act_bwd(partial_rows=...) that consumes its rows (include/mtn.h
+# mtn_bn_handover): the library fills and checks it but keeps nothing between the calls -- it lives here, one per host thread
+# (forward runs on the main thread, backward on autograd's device thread; the two calls of a hand-over are consecutive steps of
+# one backward pass on one thread).
+import ctypes as _C
+import threading as _threading
+
+_handover = _threading.local()
+
+
+def _handover_record():
+    rec = getattr(_handover, "rec", None)
+    if rec is None:
+        rec = _handover.rec = lib.BnHandover()
+    return rec
+
+
 def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None, mode=None):
     """dy [B,OH,OW,Cout] -> dx [B,H,W,Cin] (+ res, which may alias dx).
 
@@ -165,7 +182,8 @@ def conv_dgrad(dy, wt, dx, res, ksize, stride, bn=None, mode=None):
     yp, ldy = _rows(y)
     brp, ldbr = _rows(bres) if bres is not None else (0, 0)
     lib.call("mtn_conv_dgrad_bn", dyp, lddy, wt.data_ptr(), dxp, lddx, rp, ldr, yp, ldy, brp, ldbr, ss.data_ptr(),
-             mr.data_ptr(), act, partial.data_ptr(), tiles, dtype_code(dy, mode), B, H, W, Cin, Cout, ksize, stride, _stream(dy))
+             mr.data_ptr(), act, partial.data_ptr(), tiles, _C.addressof(_handover_record()), dtype_code(dy, mode), B, H, W, Cin,
+             Cout, ksize, stride, _stream(dy))
 
 
 def linear_fwd(x, w, out, bias=None, act=ACT_NONE, aux_out=None, res=None, mode=None):
@@ -275,7 +293,8 @@ def bn_act_bwd(dout, y, res, scale_shift, mean_rstd, partial, coef, dgamma, dbet
     ep, lde = _rows(extra) if extra is not None else (0, 0)
     lib.call("mtn_bn_act_bwd", dop, lddo, yp, ldy, rp, ldr, scale_shift.data_ptr(),
              mean_rstd.data_ptr(), partial.data_ptr(), coef.data_ptr(), dgamma.data_ptr(),
-             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, partial_rows, dtype_code(y, mode), M, C, act, _stream(y))
+             dbeta.data_ptr(), dyp, lddy, drp, lddr, ep, lde, partial_rows, _C.addressof(_handover_record()) if partial_rows > 0 else 0,
+             dtype_code(y, mode), M, C, act, _stream(y))
 
 
 def conv1_stats_tiles(B, H, W):

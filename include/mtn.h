@@ -89,11 +89,15 @@ int mtn_conv_dgrad(const void* dy, int lddy, const void* wt, void* dx, int lddx,
  * partial_rows = bn_tiles then skips its own reduce pass over (dout, y): one read of dx and one
  * launch less per layer.  bn_tiles must equal mtn_conv_dgrad_bn_tiles(...) (checked). */
 int mtn_conv_dgrad_bn_tiles(int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+/* (ABI 6) what a successful mtn_conv_dgrad_bn wrote, in memory the CALLER owns: it hands the record to the mtn_bn_act_bwd that
+ * consumes the rows, which checks its own arguments against it and clears it (a hand-over is used once).  The library keeps
+ * nothing between the two calls (until ABI 5 it kept this record itself, per thread). */
+typedef struct mtn_bn_handover { const float* partial; int tiles; int channels; int dtype; } mtn_bn_handover;
 int mtn_conv_dgrad_bn(const void* dy, int lddy, const void* wt, void* dx, int lddx, const void* res,
                       int ldres, const void* bn_y, int bn_ldy, const void* bn_res, int bn_ldres,
                       const float* bn_scale_shift, const float* bn_mean_rstd, int bn_act,
-                      float* bn_partial, int bn_tiles, int dtype, int B, int H, int W, int Cin,
-                      int Cout, int ksize, int stride, void* stream);
+                      float* bn_partial, int bn_tiles, mtn_bn_handover* record, int dtype, int B, int H, int W,
+                      int Cin, int Cout, int ksize, int stride, void* stream);
 
 /* Stem Conv(3,64,k3,s2) (model/gelan.py:155): reads the NCHW fp32 image batch directly, writes
  * the NHWC raw output [B][H/2][W/2][64] + stats[mtn_conv1_stats_tiles][2][64]; w packed [64][3][3][3]
@@ -178,15 +182,15 @@ int mtn_bn_act_fwd(const void* y, int ldy, const float* scale_shift, const void*
  * [mtn_bn_bwd_partial_rows(M)][2][C]; coef: f32 [2][C] scratch.  partial_rows = 0: the sums are
  * reduced here from (dout, y); partial_rows > 0: partial already holds that many rows of them
  * (mtn_conv_dgrad_bn wrote dout and the sums; the slab has mtn_slab_rows(partial_rows) rows).
- * The library records what the last mtn_conv_dgrad_bn on the calling thread wrote (slab, rows, channels)
- * and REFUSES a partial_rows > 0 call whose slab / rows / C differ from that record or that follows no
- * such launch; a record is consumed by the first mtn_bn_act_bwd(partial_rows > 0) after it. */
+ * `record` (may be NULL when partial_rows = 0): the mtn_bn_handover that mtn_conv_dgrad_bn filled.  A partial_rows > 0
+ * call whose slab / rows / C differ from the record, or whose record is empty (no such launch, or already consumed), is
+ * REFUSED; the record is cleared by the call either way. */
 int mtn_bn_bwd_partial_rows(int M);
 int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const void* res, int ldres,
                    const float* scale_shift, const float* mean_rstd, float* partial, float* coef,
                    float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
-                   const void* extra, int ldextra, int partial_rows, int dtype, int M, int C, int act,
-                   void* stream);
+                   const void* extra, int ldextra, int partial_rows, mtn_bn_handover* record, int dtype, int M,
+                   int C, int act, void* stream);
 
 /* ---- ViT encoder (model/transformer.py), dim 256 ------------------------------------------------ */
 
