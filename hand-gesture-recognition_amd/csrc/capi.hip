@@ -60,6 +60,17 @@ int mtn_conv_fwd(const void* x, int ldx, const void* w, void* y, int ldy, float*
     return mtn_igemm_run(p, dtype, (hipStream_t)stream);
 }
 
+int mtn_proj_tokens_fwd(const void* x, int ldx, const void* w, const float* pos, const float* cls, void* tok, int dtype, int B, int H,
+                        int W, int Cin, int Cout, void* stream) {
+    IgemmArgs p{};
+    const int rc = conv_fwd_args(p, "proj_tokens_fwd", B, H, W, Cin, Cout, 1, 1);
+    if (rc) return rc;
+    MTN_REQUIRE(pos && cls && tok, "proj_tokens_fwd: null operand");
+    p.A = x; p.Wp = w; p.Out = tok; p.lda = ldx; p.ldc = Cout;
+    p.tok_pos = pos; p.tok_cls = cls; p.tok_P = H * W;
+    return mtn_igemm_run(p, dtype, (hipStream_t)stream);
+}
+
 int mtn_conv_bias_act_fwd(const void* x, int ldx, const void* w, const float* bias, int act, const void* res, int ldres,
                           void* y, int ldy, int dtype, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                           void* stream) {

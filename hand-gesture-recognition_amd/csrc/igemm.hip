@@ -115,7 +115,7 @@ void igemm_kernel(IgemmArgs p) {
     // 4 = mode 1 whose epilogue multiplies by gelu'(saved pre-activation) (MTN_ACT_GELU_GRAD_): its own
     // instantiation, because the erf / exp of that epilogue cost every other one ~16 VGPRs (the 8-wave
     // 128x128 tile then no longer fits two workgroups per CU).
-    constexpr bool PW = MODE == 1 || MODE == 4;
+    constexpr bool PW = MODE == 1 || MODE == 4 || MODE == 5;      // (5 = mode 1 with the token-assembly epilogue)
     const int pm_ = (PW || MODE == 2) ? 0 : (MODE == 3 ? 1 : p.pm);
     const int KH_ = PW ? 1 : (MODE >= 2 ? 3 : p.KH), KW_ = PW ? 1 : (MODE >= 2 ? 3 : p.KW);
     T* const sA = reinterpret_cast<T*>(smem);                       // [NBUF][BM][PITCH_E]  (WIN: unused)
@@ -754,6 +754,19 @@ void igemm_kernel(IgemmArgs p) {
         if (p.act == MTN_ACT_SILU) {                   // inference with folded BatchNorm: SiLU(conv + shift [+ res])
             MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] = siluf_(v[e]);
         }
+        if constexpr (MODE == 5) {
+            // projection -> tokens: + pos[p], token-major row b*(P+1) + 1 + p; the image's first patch row also writes the class token
+            const unsigned bi = p.tok_P == 1 ? (unsigned)m : __umulhi((unsigned)m, p.tok_magic), pp = (unsigned)m - bi * (unsigned)p.tok_P;
+            MTN_UNROLL for (int e = 0; e < EV; ++e) v[e] += p.tok_pos[(long)pp * p.N + n0 + ccol + e];
+            const long trow_ = (long)m + bi + 1;
+            st_vec<T>(gO + trow_ * p.ldc + n0, ccol, v);
+            if (pp == 0) {
+                float c[EV];
+                MTN_UNROLL for (int e = 0; e < EV; ++e) c[e] = p.tok_cls[n0 + ccol + e];
+                st_vec<T>(gO + (trow_ - 1) * p.ldc + n0, ccol, c);
+            }
+            continue;
+        }
         const RawVec<T> o = pack_raw<T>(v);
         st_raw<T>(gO + (long)m * p.ldc + n0, ccol, o);
         if (p.stats) {          // statistics of the values exactly as stored
@@ -896,6 +909,9 @@ static bool igemm_pointwise(const IgemmArgs& p) {
 template <class T, int BM, int BN, int WGM, int WGN, int STG = 3>
 int launch_igemm_dma2(const IgemmArgs& p, hipStream_t stream) {
     if (igemm_pointwise(p) && p.act == MTN_ACT_GELU_GRAD_) return launch_igemm<T, BM, BN, WGM, WGN, STG, 4>(p, stream);
+    if constexpr (STG == 3 && (BM * BN == 128 * 128 || (BM == 64 && BN == 128))) {       // (the two tiles a projection can take)
+        if (igemm_pointwise(p) && p.tok_pos) return launch_igemm<T, BM, BN, WGM, WGN, STG, 5>(p, stream);
+    }
     if (igemm_pointwise(p)) return launch_igemm<T, BM, BN, WGM, WGN, STG, 1>(p, stream);
     if (p.KH == 3 && p.KW == 3) return p.pm ? launch_igemm<T, BM, BN, WGM, WGN, STG, 3>(p, stream) : launch_igemm<T, BM, BN, WGM, WGN, STG, 2>(p, stream);
     return launch_igemm<T, BM, BN, WGM, WGN, STG>(p, stream);
@@ -1088,6 +1104,13 @@ int mtn_igemm_run(const IgemmArgs& p0, int dtype, hipStream_t stream) {
                      p.lda % 32 == 0 && p.ldc % 32 == 0 && (!p.res || p.ldr % 32 == 0) && (!p.aux_out || p.ld_aux % 32 == 0) &&
                      (!p.bn_y || p.bn_ldy % 32 == 0) && (!p.bn_res || p.bn_ldr % 32 == 0)),
                 "igemm: split storage (MTN_DTYPE_F32X3) needs 16-byte aligned operands and row pitches that are multiples of 32");
+    if (p.tok_pos) {
+        MTN_REQUIRE(igemm_pointwise(p) && p.tok_cls && p.tok_P > 0 && p.M % p.tok_P == 0 && !p.stats && !p.res && !p.bias && !p.aux_out &&
+                        p.act == MTN_ACT_NONE && p.N % 128 == 0 && (g_igemm_stages == 5 || g_igemm_stages >= 7),
+                    "igemm: the token epilogue serves a plain pointwise product whose rows are whole images of %d patches", p.tok_P);
+        MTN_REQUIRE((long)p.M * p.tok_P < (1L << 32), "igemm: M * P too large for the multiply-high image index");
+        p.tok_magic = p.tok_P > 1 ? (unsigned)(0x100000000ull / (unsigned)p.tok_P) + 1u : 0u;
+    }
     if (mtn_dgrad2_ok(p, dtype)) return mtn_dgrad2_run(p, dtype, stream);     // 3x3 stride-2 data gradient: dgrad2.hip
     if (mtn_pw_ok(p, dtype)) return mtn_pw_run(p, dtype, stream);             // short-K pointwise products: pw.hip
     if (mtn_win3_ok(p, dtype)) return mtn_win3_run(p, dtype, stream);         // 64 -> 64 channel 3x3 stride-1 layers: win3.hip

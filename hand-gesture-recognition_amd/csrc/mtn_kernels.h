@@ -38,6 +38,10 @@ struct IgemmArgs {
     const float* bn_ss;   // [2][N] scale, shift
     const float* bn_mr;   // [2][N] mean, rstd
     int bn_act;
+    // Token assembly in the epilogue (pointwise launches only): Out is the ViT token tensor [B][tok_P + 1][N]; row
+    // m = (b, p) is written to token row b*(tok_P+1) + 1 + p with tok_pos[p][n] added, and the rows p = 0 also write the class
+    // token tok_cls[n] to row b*(tok_P+1) (model/transformer.py:132-139).  tok_magic: multiply-high divisor of m / tok_P.
+    const float* tok_pos; const float* tok_cls; int tok_P; unsigned tok_magic;
     int pm;               // rows in parity-major order (stride-2 dgrad tap skipping)
     int win_cs;           // filled at launch (window mode): resident 128-byte channel slabs of the activation window
     unsigned magic_w, magic_h;   // filled by mtn_igemm_run: multiply-high divisors of the row decode

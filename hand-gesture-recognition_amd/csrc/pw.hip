@@ -268,7 +268,7 @@ bool mtn_pw_ok(const IgemmArgs& p, int dtype) {
     if (p.N % PW_BN || p.M % PW_BM) return false;
     if (dtype == MTN_BF16 ? (p.K != 128 && p.K != 256 && !(p.K == 512 && g_pw == 2)) : p.K != 128) return false;
     if (g_pw != 2 && p.M / PW_BM < 16 * pw_walkers(p)) return false;
-    if (p.res || p.bn_y || p.act == MTN_ACT_GELU_GRAD_) return false;
+    if (p.res || p.bn_y || p.act == MTN_ACT_GELU_GRAD_ || p.tok_pos) return false;
     if ((size_t)p.M * p.lda * (dtype == MTN_BF16 ? 2 : 4) >= (1ull << 32) - (1u << 20)) return false;      // 32-bit buffer offsets
     return true;
 }

@@ -67,6 +67,8 @@ class Engine:
         # LayerNorm / bias gradients of the ViT are leaves: their partial-sum slabs are folded by ONE grouped call at the end
         # of the bucket instead of two launches per slab (MTN_DEFER_LEAF_SUMS=0: fold each one where it is produced)
         self.defer_leaf_sums = os.environ.get("MTN_DEFER_LEAF_SUMS", "1") != "0"
+        # the token assembly in the projection's epilogue (MTN_FUSE_TOKENS=0: projection, then the tokens_fwd launch)
+        self.fuse_tokens = os.environ.get("MTN_FUSE_TOKENS", "1") != "0"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -422,15 +424,22 @@ class Engine:
             self.fold_batchnorm()
         feats = self.backbone_forward(x, training)
         up = self.u_proj
+        if self.fuse_tokens:
+            # multitasknet.py:26 + transformer.py:132-139 in one launch: the projection's epilogue adds the position embedding,
+            # writes token-major rows and the class token; the projected features are never stored
+            self.o.proj_tokens_fwd(feats, up.wf, self.pos, self.model.decoder.cls_token, self.x[0])
+            return self.vit_forward(want_attn, tokens_ready=True)
         self.o.conv_fwd(feats, up.wf, up.raw, None, 1, 1)                                   # multitasknet.py:26
         return self.vit_forward(want_attn)
 
-    def vit_forward(self, want_attn=True):
+    def vit_forward(self, want_attn=True, tokens_ready=False):
         """ViT.forward (model/transformer.py:129-152) on the projected features in ``self.feat`` ([B*P, 256], the plan's
-        storage): -> (logits, heatmaps, attnmap).  The packed weights must be current (pack_weights / fold_batchnorm)."""
+        storage): -> (logits, heatmaps, attnmap).  The packed weights must be current (pack_weights / fold_batchnorm).
+        ``tokens_ready``: forward() already assembled the tokens in the projection's epilogue."""
         dec = self.model.decoder
         self.serial[1] += 1
-        self.o.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                    # transformer.py:132-139
+        if not tokens_ready:
+            self.o.tokens_fwd(self.feat, self.pos, dec.cls_token, self.x[0])                # transformer.py:132-139
         B, N, D, Hh = self.B, self.N, self.dim, self.heads
         Mt = B * N
         for i, L in enumerate(self.layers):

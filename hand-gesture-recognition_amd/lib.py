@@ -48,6 +48,7 @@ _PROTOS = {
     "mtn_linear_gelu_bwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "mtn_bn_act_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                        _i, _vp, _i, _i, _i, _i, _vp],
+    "mtn_proj_tokens_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_tokens_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_tokens_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mtn_layernorm_fwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _f, _vp],

@@ -366,6 +366,20 @@ def conv1_dx(x_nchw, w_oihw, dout, scale_shift, mean_rstd, dgamma, dbeta, dx, ac
 
 
 # ---- ViT encoder --------------------------------------------------------------------------------
+def proj_tokens_fwd(x, w, pos, cls, tok, mode=None):
+    """tok[b, 0] = cls ; tok[b, 1 + p] = (x[b] @ w.T)[p] + pos[p]: the 1x1 projection with the token assembly in its epilogue
+    (x [B,H,W,Cin], w packed [Cout, Cin], pos f32 [H*W, Cout], cls f32 [Cout] (any shape), tok [B, H*W + 1, Cout])."""
+    B, H, W, Cin = x.shape
+    Cout = tok.shape[-1]
+    if tuple(tok.shape) != (B, H * W + 1, Cout) or not tok.is_contiguous() or tok.dtype != x.dtype:
+        raise ValueError(f"proj_tokens_fwd: tok must be a contiguous [{B}, {H * W + 1}, Cout] tensor of x's dtype")
+    if pos.dtype != torch.float32 or tuple(pos.shape) != (H * W, Cout) or not pos.is_contiguous() or cls.dtype != torch.float32 or cls.numel() != Cout:
+        raise ValueError("proj_tokens_fwd: pos must be f32 [H*W, Cout], cls f32 with Cout elements")
+    xp, ldx = _rows(x)
+    lib.call("mtn_proj_tokens_fwd", xp, ldx, w.data_ptr(), pos.data_ptr(), cls.data_ptr(), tok.data_ptr(), dtype_code(x, mode),
+             B, H, W, Cin, Cout, _stream(x))
+
+
 def tokens_fwd(feat, pos, cls, tok, mode=None):
     """feat [B*P,256] (+pos f32 [P,256]) and cls f32 [256] -> tok [B,P+1,256]."""
     B, P1, _ = tok.shape

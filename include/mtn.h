@@ -194,6 +194,12 @@ int mtn_bn_act_bwd(const void* dout, int lddo, const void* y, int ldy, const voi
 
 /* ---- ViT encoder (model/transformer.py), dim 256 ------------------------------------------------ */
 
+/* (ABI 6) the 1x1 projection (model/multitasknet.py:13,26) and the token assembly (model/transformer.py:132-139) as ONE launch
+ * (SURVEY K5): tok f32/T [B][H*W + 1][Cout] receives, per image, the class token in row 0 and conv1x1(x)[p] + pos[p] in row
+ * 1 + p; pos f32 [H*W][Cout], cls f32 [Cout]; x [B][H][W][Cin] with pixel stride ldx, w packed [Cout][Cin].  Cout % 128 == 0.
+ * (= mtn_conv_fwd(k = 1) into a feature tensor + mtn_tokens_fwd, without the feature tensor's round trip.) */
+int mtn_proj_tokens_fwd(const void* x, int ldx, const void* w, const float* pos, const float* cls, void* tok, int dtype,
+                        int B, int H, int W, int Cin, int Cout, void* stream);
 /* tokens[b][0] = cls_token, tokens[b][1+p] = feat[b*P+p] + pos[p]   (transformer.py:132-139) */
 int mtn_tokens_fwd(const void* feat, const float* pos, const float* cls, void* tok, int dtype, int B,
                    int P, void* stream);

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import DTYPES, GEMM_DTYPES, A, Fl, be, dbg, rel_err, tol  # noqa: F401
+from backend import DTYPES, GEMM_DTYPES, A, Fl, be, dbg, rel_err, tol, x3_active  # noqa: F401
 from hand_gesture_recognition_amd import ops
 
 
@@ -31,6 +31,40 @@ def test_tokens(be, dtype):
     be.sync()
     assert rel_err(Fl(dfeat), dtok[:, 1:].float().reshape(B * P, 256)) < tol(dtype, 1e-6, 1e-6)
     assert rel_err(dcls, dtok[:, 0].float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", GEMM_DTYPES)
+@pytest.mark.parametrize("cfg", [(3, 3, 3, 128, 256), (2, 12, 12, 512, 256), (5, 1, 1, 64, 256), (1, 6, 4, 64, 256), (70, 12, 12, 64, 256)])
+def test_projection_writes_the_tokens(be, dtype, cfg):
+    """SURVEY K5 (mtn_proj_tokens_fwd): the 1x1 projection with + pos, the token-major rows and the class token in its epilogue
+    against torch, and against the two-launch form (projection into a feature tensor, then tokens_fwd): identical for f32
+    storage, one rounding apart for bf16 (the fused form rounds conv + pos once).  Shapes: images smaller / larger than a
+    64-row tile, a one-patch image (P = 1), a non-square map, and > 8192 rows (the 8-wave 128x128 tile)."""
+    B, H, W, Cin, Cout = cfg
+    if be.name == "emu" and B * H * W > 600:
+        pytest.skip("the 128x128-tile case is for the GPU")
+    d, P = be.device, H * W
+    x = _rand((B, H, W, Cin), dtype, 31)
+    w = _rand((Cout, Cin), torch.float32, 32) / Cin ** 0.5
+    pos, cls = _rand((P, Cout), torch.float32, 33), _rand((1, 1, Cout), torch.float32, 34)
+    from test_conv_kernels import _wfmt
+    wd = _wfmt(w, dtype).to(d)
+    ref = torch.cat([cls.expand(B, 1, Cout), (x.float().reshape(B, P, Cin) @ w.to(dtype).float().t()) + pos], 1)
+    tok = torch.full((B, P + 1, Cout), float("nan"), dtype=dtype, device=d)
+    ops.proj_tokens_fwd(A(x).to(d), wd, pos.to(d), cls.to(d), tok)
+    be.sync()
+    assert rel_err(Fl(tok), ref) < tol(dtype, 1e-5, 1e-2)
+    feat = torch.empty((B, H, W, Cout), dtype=dtype, device=d)
+    ops.conv_fwd(A(x).to(d), wd, feat, None, 1, 1)
+    tok2 = torch.empty_like(tok)
+    ops.tokens_fwd(feat.view(B * P, Cout), pos.to(d), cls.to(d), tok2)
+    be.sync()
+    if dtype == torch.float32 and not x3_active():
+        assert torch.equal(tok.cpu(), tok2.cpu())
+    else:
+        assert rel_err(Fl(tok), Fl(tok2)) < tol(dtype, 1e-5, 1e-2)
+    with pytest.raises(ValueError):
+        ops.proj_tokens_fwd(A(x).to(d), wd, pos.to(d)[:-1], cls.to(d), tok)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
