@@ -129,14 +129,21 @@ def igemm_roofline(step, batch, mode="bf16"):
         fam = ops.conv_kernel_family(dt, False, M, 1, 1, K, N, 1, 1, has_res=res is not None, mode=fcode)
         return 2.0 * M * N * K, nbytes(x, w, out, aux_out, res), 1, fam
 
-    saved = (ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd)
-    ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = (wrap("conv_fwd", saved[0], g_fwd), wrap("conv_dgrad", saved[1], g_dgrad),
-                                                    wrap("linear", saved[2], g_lin))
+    def g_proj(x, w, pos, cls, tok, **kw):      # the 1x1 projection with the token assembly in its epilogue: an igemm_kernel launch
+        B, H, W, Cin = x.shape
+        Cout = tok.shape[-1]
+        fam = ops.conv_kernel_family(dt, False, B, H, W, Cin, Cout, 1, 1, mode=fcode)
+        return 2.0 * B * H * W * Cout * Cin, nbytes(x, w, tok, pos), 1, (0 if fam == 3 else fam)      # (never the persistent kernel: pw.hip)
+
+    saved = (ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd, ops.proj_tokens_fwd)
+    ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd, ops.proj_tokens_fwd = (
+        wrap("conv_fwd", saved[0], g_fwd), wrap("conv_dgrad", saved[1], g_dgrad), wrap("linear", saved[2], g_lin),
+        wrap("proj_tokens", saved[3], g_proj))
     try:
         step._eager(*batch)
         torch.cuda.synchronize()
     finally:
-        ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd = saved
+        ops.conv_fwd, ops.conv_dgrad, ops.linear_fwd, ops.proj_tokens_fwd = saved
     # (flops, algorithmic bytes, kernel size, seconds) per launch, grouped by the kernel source that served it
     by = {}
     for name, (fl, by_, k, famc), e0, e1 in rec:
