@@ -878,7 +878,7 @@ int launch_igemm(const IgemmArgs& p, hipStream_t stream) {
     size_t lds = lds0 > lds_r ? lds0 : lds_r;
     int win_cs = 0;
     if (STAGES == 5 || STAGES == 6) {
-        win_cs = STAGES == 6 ? igemm_image_tile_cs(p, (int)sizeof(T)) : (BM * BN == 128 * 128 ? 2 : igemm_window_cs(p, (int)sizeof(T), BM, BN));
+        win_cs = STAGES == 6 ? igemm_image_tile_cs(p, (int)sizeof(T)) : ((BM == 128 && BN == 128) ? 2 : igemm_window_cs(p, (int)sizeof(T), BM, BN));
         const size_t win = igemm_window_bytes(p, BM, STAGES == 6 ? 0 : BN, win_cs);
         const size_t rest = lds_c > lds_r ? lds_c : lds_r;
         lds = win > rest ? win : rest;
@@ -960,6 +960,13 @@ static int igemm_config(int M, int N, int K) {
     return 3;
 }
 
+// bf16, 64 -> 64 channels: the 256x64 window tile on eight waves, where it fills at least two rounds of its 512 workgroup slots
+// (debug key 8 = 7: whatever the size -- tests); the 128x64 tile otherwise
+static bool igemm_window256_ok(const IgemmArgs& p) {
+    return g_igemm_stages == 5 && g_igemm_dbg != 8 && igemm_window_shape(p) && p.Cin == 64 && p.N == 64 &&
+           (p.M >= 256 * 1024 || g_igemm_dbg == 7) && igemm_window_bytes(p, 256, 64, 1) <= 79 * 1024;      // (debug key 8 = 8: off)
+}
+
 // bf16, 128x128 tile: window mode with both 64-channel slabs of a 128-channel layer resident, while two workgroups still fit a CU
 static bool igemm_window128_ok(const IgemmArgs& p) {
     return g_igemm_stages == 5 && igemm_window_shape(p) && p.Cin == 128 && igemm_window_bytes(p, 128, 128, 2) <= 79 * 1024;
@@ -1004,6 +1011,13 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     if (cfg == 2) return launch_igemm_mode<T, 256, 64, 4, 1>(p, stream);
 #endif
     if (cfg == 1) return launch_igemm_mode<T, 64, 128, 1, 4>(p, stream);
+    // 64 -> 64 channel 3x3 stride-1 layers (stage 1) on a 256x64 window tile with EIGHT waves (8 x 1: 32 x 64 per wave), two workgroups
+    // per CU (round 5): halo 1.38x instead of 1.77x of the tile rows, the weight tiles streamed once per 256 rows, prologue and
+    // epilogue once per 256 rows.  Round 1 measured 256x64 with four waves and without the window (-5..8 %), round 2 with the window
+    // (-30 %); with eight waves: forward 78.3 -> 72.4 us, data gradient 87.5 -> 75.7, step -0.045 ms (profiles/r05_window256_ab.txt)
+    if constexpr (sizeof(T) == 2 || std::is_same<T, f32x3_t>::value) {      // (split storage: one resident 32-channel slab, two passes)
+        if (igemm_window256_ok(p)) return launch_igemm<T, 256, 64, 8, 1, 5, 2>(p, stream);
+    }
     return launch_igemm_mode<T, 128, 64, 4, 1>(p, stream);
 }
 }  // namespace
@@ -1044,6 +1058,7 @@ int mtn_igemm_stats_tiles(const IgemmArgs& p, int dtype) {
     if (mtn_pw_ok(p, dtype)) return mtn_pw_rows(p);
     if (mtn_win3_ok(p, dtype)) return mtn_win3_rows(p);
     if (igemm_image_tile_ok(p, dtype)) return mtn_cdiv(p.M, IMG_BM);
+    if ((dtype == MTN_BF16 || dtype == MTN_F32X3) && igemm_window256_ok(p)) return mtn_cdiv(p.M, 256);
     if (dtype == MTN_BF16 && ((g_igemm_stages == 7 && g_igemm_tile == 4) || (g_igemm_stages == 5 && g_igemm_tile >= 5)) && igemm_config(p.M, p.N, p.K) == 0)
         return mtn_cdiv(p.M, 256);
     return mtn_igemm_tiles_m(p.M, p.N, p.K);
@@ -1058,6 +1073,7 @@ int mtn_igemm_family(const IgemmArgs& p, int dtype) {
     const int esz = dtype == MTN_BF16 ? 2 : 4;
     if (g_igemm_stages == 5 && !p.pm && igemm_window_shape(p)) {
         static const int bm[4] = {128, 64, 256, 128}, bn[4] = {128, 128, 64, 64};
+        if ((dtype == MTN_BF16 || dtype == MTN_F32X3) && igemm_window256_ok(p)) return MTN_KERNEL_IGEMM_WINDOW;
         const int cfg = igemm_config(p.M, p.N, p.K);      // (the 8-wave 128x128 tile: bf16 layers of 128 channels only, dispatch_igemm)
         if (cfg == 0 ? (dtype == MTN_BF16 && igemm_window128_ok(p)) : igemm_window_ok(p, bm[cfg], bn[cfg], esz)) return MTN_KERNEL_IGEMM_WINDOW;
     }

@@ -809,3 +809,54 @@ def test_conv3x3_persistent_kernel(be, win3_forced, cfg):
     assert torch.equal(dxr.view(torch.int16), dxr0.view(torch.int16))
     scale = float(pt0.abs().max()) + 1e-6
     assert float((pt - pt0).abs().max()) < 2e-4 * scale, (pt, pt0)
+
+
+@pytest.mark.parametrize("dtype", [pytest.param(torch.bfloat16, id="bf16"), pytest.param(torch.float32, id="x3", marks=pytest.mark.x3)])
+@pytest.mark.parametrize("cfg", [(2, 12, 12), (1, 48, 20), (3, 5, 7), (9, 8, 8)])
+def test_conv_window_256x64_tile(be, dtype, cfg):
+    """Round 5: 64 -> 64 channel 3x3 stride-1 layers on the 256 x 64 window tile with eight waves (debug key 8 = 7 lifts its size
+    floor: the model reaches it at >= 262,144 rows).  Forward with statistics, data gradient with a residual, and the data
+    gradient's BatchNorm hand-over against the 128 x 64 tile's results."""
+    B, H, W = cfg
+    C, d = 64, be.device
+    x = _rand((B, H, W, C), dtype, 61)
+    w = _rand((C, C, 3, 3), torch.float32, 62) / (C * 9) ** 0.5
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dtype).float(), None, 1, 1).permute(0, 2, 3, 1)
+    M = B * H * W
+    xz = torch.zeros((B, C, H, W), requires_grad=True)
+    dyv, res = _rand((B, H, W, C), dtype, 63), _rand((B, H, W, C), dtype, 64)
+    F.conv2d(xz, w.to(dtype).float(), None, 1, 1).backward(dyv.float().permute(0, 3, 1, 2))
+    dref = xz.grad.permute(0, 2, 3, 1) + res.float()
+    raw = A(_rand((B, H, W, C), dtype, 65) * 1.5 + 0.2).to(d)
+    ss = torch.stack([torch.rand(C) + 0.5, torch.randn(C) * 0.2]).to(d)
+    mr = torch.stack([torch.randn(C) * 0.1, torch.rand(C) + 0.5]).to(d)
+    got = {}
+    for key in (0, 7):
+        dbg(8, key)
+        try:
+            assert ops.conv_kernel_family(dtype, False, B, H, W, C, C, 3, 1) == 1
+            tiles = ops.conv_fwd_stats_tiles(dtype, B, H, W, C, C, 3, 1)
+            assert tiles == (M + 255) // 256 if key == 7 else tiles == (M + 127) // 128
+            y = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=d)
+            stats = torch.full((tiles, 2, C), float("nan"), device=d)
+            ops.conv_fwd(A(x).to(d), pack_krsc(w, dtype).to(d), y, stats, 3, 1, stats_tiles=tiles)
+            dx = A(res).clone().to(d)
+            ops.conv_dgrad(A(dyv).to(d), pack_crsk(w, dtype).to(d), dx, dx, 3, 1)
+            dtiles = ops.conv_dgrad_bn_tiles(dtype, B, H, W, C, C, 3, 1)
+            part = torch.full((ops.slab_rows(dtiles), 2, C), float("nan"), device=d)
+            dx2 = torch.empty((B, H, W, C), dtype=dtype, device=d)
+            ops.conv_dgrad(A(dyv).to(d), pack_crsk(w, dtype).to(d), dx2, None, 3, 1, bn=(raw, None, ss, mr, ops.ACT_SILU, part, dtiles))
+            be.sync()
+            got[key] = (y.cpu(), stats.cpu().sum(0), dx.cpu(), dx2.cpu(), part[:dtiles].cpu().sum(0))
+        finally:
+            dbg(8, 0)
+    y, st, dx, dx2, ps = got[7]
+    assert rel_err(Fl(y), ref) < tol(dtype) and rel_err(Fl(dx), dref) < tol(dtype)
+    yf = Fl(y).reshape(M, C)
+    assert rel_err(st[0], yf.sum(0)) < 1e-3 and rel_err(st[1], (yf * yf).sum(0)) < 1e-3
+    # the same values as the 128 x 64 tile writes (same products, same K order), sums in another tile grouping
+    if dtype == torch.bfloat16:
+        assert torch.equal(y, got[0][0]) and torch.equal(dx, got[0][2]) and torch.equal(dx2, got[0][3])
+    else:       # (split storage: the 128 x 64 tile may keep both 32-channel slabs resident -- another K order of the f32 accumulation)
+        assert rel_err(Fl(y), Fl(got[0][0])) < 3e-5 and rel_err(Fl(dx), Fl(got[0][2])) < 3e-5 and rel_err(Fl(dx2), Fl(got[0][3])) < 3e-5
+    assert rel_err(ps, got[0][4]) < 1e-4 and rel_err(st, got[0][1]) < 1e-4
