@@ -1002,6 +1002,7 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     // 16 KB weight tiles = 78 KB, two workgroups per CU as before.  Round 2 measured the window at 128x128 with FOUR waves (+4 %),
     // the 8-wave tile came later (+5..9 %); together: forward 65.2 -> 64.0 us, step -0.035 ms (profiles/r05_window128_ab.txt)
     if constexpr (sizeof(T) == 2) {
+        // (a 256x128 window tile with SIXTEEN waves, one workgroup per CU, measured slower: forward 64 -> 76 us, profiles/r05_window256_ab.txt)
         if (cfg == 0 && igemm_window128_ok(p)) return launch_igemm<T, 128, 128, 4, 2, 5, 2>(p, stream);
     }
     if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages >= 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
