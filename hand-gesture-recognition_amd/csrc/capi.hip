@@ -486,6 +486,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 24) { mtn_bn_set_fwd_order(value); return MTN_OK; }
     if (key == 25) { mtn_pose_set_bands(value); return MTN_OK; }
     if (key == 28) { mtn_wgrad_set_slab_bf16(value); return MTN_OK; }
+    if (key == 29) { mtn_wgrad_set_ks256(value); return MTN_OK; }
     if (key == 26 || key == 27) {
 #ifdef MTN_EXPERIMENTS
         if (key == 26) mtn_bn_set_ticket(value);

@@ -83,6 +83,7 @@ struct WgradArgs {
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);
 void mtn_wgrad_set_tr16(int on);
+void mtn_wgrad_set_ks256(int on);
 void mtn_conv1_set_x3(int v);
 void mtn_wgrad_set_x3_sep(int on);
 

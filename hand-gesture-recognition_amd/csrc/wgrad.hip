@@ -646,9 +646,13 @@ template <class T> struct Wg3 {
 // piece between the K-sub-steps of step t.  (One workgroup per CU, not two: every workgroup writes its
 // 64 x 576 f32 partial tile to the slab, so the slab -- written here, read back by wgrad_reduce -- is
 // 147 KB x workgroups; at 512 workgroups that was 75 MB per layer, as many bytes as the operands.)
-template <class T>
+// KSX / WMAX (round 5): slots per step and the widest map the two stages are sized for -- 256 slots per step for bf16 maps up to
+// 48 wide (2 x 79 KB of stages): halo 1.39x instead of 1.78x of the step's slots, half the barriers and DMA batches per slot
+// (68-72 us per layer instead of 72-79, step -0.02 ms: profiles/r05_misc_ab.txt)
+template <class T, int KSX = Wg3<T>::KS, int WMAX = Wg3<T>::MAXW>
 __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
-    constexpr int KS = Wg3<T>::KS, VEC = Wg3<T>::VEC, CPR = Wg3<T>::CPR, RPB = Wg3<T>::RPB;
+    constexpr int KS = KSX, VEC = Wg3<T>::VEC, CPR = Wg3<T>::CPR, RPB = Wg3<T>::RPB;
+    constexpr int STG = (2 * KS + 2 * (WMAX + 2) + RPB) * 64;
     constexpr int KI = Mma<T>::KI;
     constexpr int SUB = 32;                                       // slots per K-sub-step of the MFMA loop
     constexpr int NSUB = KS / SUB;
@@ -659,8 +663,8 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
     // and a runtime stage offset hipcc cannot tell them apart and puts `s_waitcnt vmcnt(0)` in front
     // of the first fragment read after every DMA issue (an LDS-DMA is an LDS write to the compiler):
     // the prefetch then hides nothing (cdna_hip_programming.md section 5, trap 4a).
-    __shared__ __attribute__((aligned(16))) T sStage0[Wg3<T>::STAGE];
-    __shared__ __attribute__((aligned(16))) T sStage1[Wg3<T>::STAGE];
+    __shared__ __attribute__((aligned(16))) T sStage0[STG];
+    __shared__ __attribute__((aligned(16))) T sStage1[STG];
     const int W1 = p.W + 1, H1 = p.H + 1, HALO = W1 + 1;
     const int WR = (KS + 2 * HALO + RPB - 1) / RPB * RPB;         // window rows, whole DMA pieces
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -933,6 +937,8 @@ int launch_wgrad_row3(const WgradArgs& p, hipStream_t stream) {
     return mtn_check_launch("wgrad_row3");
 }
 
+static int g_wgrad3_ks256 = 1;   // debug key 29: 0 = 128 slots per step for every bf16 map (default: 256 for maps up to 48 wide)
+static int mtn_wgrad3_ks(int dtype, int W) { return dtype == MTN_BF16 ? ((g_wgrad3_ks256 && W <= 48) ? 256 : 128) : 64; }
 template <class T>
 int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
     constexpr int KS = Wg3<T>::KS, RPB = Wg3<T>::RPB;
@@ -940,6 +946,13 @@ int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
     const int wr = (KS + 2 * halo + RPB - 1) / RPB * RPB;
     MTN_REQUIRE((KS + wr) * 64 <= Wg3<T>::STAGE, "wgrad3: window of a %d-wide map does not fit", p.W);
     const int tiles = (p.N / 64) * (p.Cin / 64);
+    if constexpr (sizeof(T) == 2) {
+        if (mtn_wgrad3_ks(MTN_BF16, p.W) == 256) {
+            MTN_REQUIRE(p.rows_per_split % 256 == 0, "wgrad3: %d slots per split for 256-slot steps", p.rows_per_split);
+            MTN_LAUNCH((wgrad3_kernel<T, 256, 48>), dim3(tiles * p.splits), dim3(512), 0, stream, p);
+            return mtn_check_launch("wgrad3");
+        }
+    }
     MTN_LAUNCH(wgrad3_kernel<T>, dim3(tiles * p.splits), dim3(512), 0, stream, p);
     return mtn_check_launch("wgrad3");
 }
@@ -949,6 +962,7 @@ int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
 static int g_use_tr16 = 1;
 static int g_wgrad3 = 1;         // debug key 13: 0 = per-tap tiles for 3x3 stride-1 layers too
 void mtn_wgrad_set_win(int on) { g_wgrad3 = on; }
+void mtn_wgrad_set_ks256(int on) { g_wgrad3_ks256 = on ? 1 : 0; }
 
 // the window kernel serves 3x3 / stride 1 / pad 1 layers whose two window stages fit the LDS of a CU
 int mtn_wgrad3_ok(int dtype, int H, int W, int ksize, int stride) {
@@ -959,7 +973,7 @@ int mtn_wgrad3_ok(int dtype, int H, int W, int ksize, int stride) {
 
 // split of the padded slot axis: one workgroup per CU
 int mtn_wgrad3_splits(int B, int H, int W, int N, int Cin, int dtype, int* slots_per_split) {
-    const int ks = dtype == MTN_BF16 ? 128 : 64;
+    const int ks = mtn_wgrad3_ks(dtype, W);
     const long S = (long)B * (H + 1) * (W + 1);
     const long tiles = (long)(N / 64) * (Cin / 64);
     long splits = (g_wgrad_slots > 0 ? g_wgrad_slots : 256) / tiles;

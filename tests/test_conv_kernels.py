@@ -860,3 +860,31 @@ def test_conv_window_256x64_tile(be, dtype, cfg):
     else:       # (split storage: the 128 x 64 tile may keep both 32-channel slabs resident -- another K order of the f32 accumulation)
         assert rel_err(Fl(y), Fl(got[0][0])) < 3e-5 and rel_err(Fl(dx), Fl(got[0][2])) < 3e-5 and rel_err(Fl(dx2), Fl(got[0][3])) < 3e-5
     assert rel_err(ps, got[0][4]) < 1e-4 and rel_err(st, got[0][1]) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 6, 64, 64), (1, 12, 12, 64, 128), (3, 5, 7, 128, 64), (2, 24, 24, 64, 64), (1, 4, 50, 64, 64)])
+def test_conv_wgrad_window_kernel_step_sizes(be, cfg):
+    """wgrad3_kernel with 256 slots per step (bf16 maps up to 48 wide, the default since round 5) and with 128 (debug key 29 = 0;
+    a 50-wide map takes 128 either way): both against torch, f32 partial tiles so that the two agree to summation order."""
+    B, H, W, Cin, Cout = cfg
+    dtype, d = torch.bfloat16, be.device
+    x = _rand((B, H, W, Cin), dtype, 12)
+    w = torch.zeros((Cout, Cin, 3, 3), requires_grad=True)
+    yref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 1)
+    dy = _rand(tuple(yref.permute(0, 2, 3, 1).shape), dtype, 13)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    got = []
+    for key in (1, 0):
+        dbg(29, key)
+        dbg(28, 0)
+        try:
+            assert ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 3, 1) > 0
+            ws = torch.empty(ops.conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, 3, 1) // 4, dtype=torch.float32, device=d)
+            dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=d)
+            ops.conv_wgrad(x.to(d), dy.to(d), dw, ws, 3, 1)
+            be.sync()
+            got.append(dw.cpu())
+        finally:
+            dbg(29, 1)
+            dbg(28, 1)
+    assert rel_err(got[0], w.grad) < 1e-5 and rel_err(got[1], w.grad) < 1e-5 and rel_err(got[0], got[1]) < 1e-5
