@@ -1001,9 +1001,10 @@ int dispatch_igemm(const IgemmArgs& p, hipStream_t stream) {
     // the window mode on the 8-wave 128x128 tile (round 5): the stage-2 3x3 layers -- 128 channels at 24x24: 45 KB of window + two
     // 16 KB weight tiles = 78 KB, two workgroups per CU as before.  Round 2 measured the window at 128x128 with FOUR waves (+4 %),
     // the 8-wave tile came later (+5..9 %); together: forward 65.2 -> 64.0 us, step -0.035 ms (profiles/r05_window128_ab.txt)
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 || std::is_same<T, f32x3_t>::value) {
         // (a 256x128 window tile with SIXTEEN waves, one workgroup per CU, measured slower: forward 64 -> 76 us, profiles/r05_window256_ab.txt)
-        if (cfg == 0 && igemm_window128_ok(p)) return launch_igemm<T, 128, 128, 4, 2, 5, 2>(p, stream);
+        // (split storage: two of the four 32-channel blocks resident, two passes over the window; debug key 8 = 10: bf16 only)
+        if (cfg == 0 && igemm_window128_ok(p) && (sizeof(T) == 2 || g_igemm_dbg != 10)) return launch_igemm<T, 128, 128, 4, 2, 5, 2>(p, stream);
     }
     if (cfg == 0 && (g_igemm_stages == 5 || g_igemm_stages >= 7)) return launch_igemm_dma2<T, 128, 128, 4, 2>(p, stream);
 #ifdef MTN_EXPERIMENTS
@@ -1076,7 +1077,8 @@ int mtn_igemm_family(const IgemmArgs& p, int dtype) {
         static const int bm[4] = {128, 64, 256, 128}, bn[4] = {128, 128, 64, 64};
         if ((dtype == MTN_BF16 || dtype == MTN_F32X3) && igemm_window256_ok(p)) return MTN_KERNEL_IGEMM_WINDOW;
         const int cfg = igemm_config(p.M, p.N, p.K);      // (the 8-wave 128x128 tile: bf16 layers of 128 channels only, dispatch_igemm)
-        if (cfg == 0 ? (dtype == MTN_BF16 && igemm_window128_ok(p)) : igemm_window_ok(p, bm[cfg], bn[cfg], esz)) return MTN_KERNEL_IGEMM_WINDOW;
+        if (cfg == 0 ? ((dtype == MTN_BF16 || (dtype == MTN_F32X3 && g_igemm_dbg != 10)) && igemm_window128_ok(p)) : igemm_window_ok(p, bm[cfg], bn[cfg], esz))
+            return MTN_KERNEL_IGEMM_WINDOW;
     }
     return MTN_KERNEL_IGEMM;
 }

@@ -215,7 +215,7 @@ def test_conv_fwd_forced_128x128_tile(be, dtype, cfg):
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dtype).float(), None, s, k // 2).permute(0, 2, 3, 1)
     OH, OW = ref.shape[1:3]
     M = B * OH * OW
-    win128 = dtype == torch.bfloat16 and k == 3 and s == 1 and Cin == 128        # (round 5: this tile's window form)
+    win128 = (dtype == torch.bfloat16 or x3_active()) and k == 3 and s == 1 and Cin == 128        # (round 5: this tile's window form)
     dx = dref = None
     dbg(6, 1)
     try:
