@@ -29,7 +29,9 @@ BUDGETS = [
     ("igemm_kernel<bf16_t, 128, 64, 4, 1, 5, 2>", 168, "window mode: 3 workgroups per CU (53 KB of LDS each)"),
     ("dgrad2_kernel<bf16_t>", 128, "8 waves x 2 workgroups per CU"),
     ("wgrad_dma2_kernel<bf16_t, 128, 128, 4, 2, false>", 128, "8 waves x 2 workgroups per CU"),
-    ("wgrad3_kernel<bf16_t>", 256, "8 waves, one workgroup per CU"),
+    ("wgrad3_kernel<bf16_t,", 256, "8 waves, one workgroup per CU (128 and 256 slots per step)"),
+    ("igemm_kernel<bf16_t, 128, 128, 4, 2, 5, 2>", 128, "window mode on the 8-wave tile: 2 workgroups per CU (78 KB of LDS each)"),
+    ("igemm_kernel<bf16_t, 256, 64, 8, 1, 5, 2>", 128, "256x64 window tile: 8 waves x 2 workgroups per CU"),
     ("wgrad_row3_kernel<bf16_t>", 256, "4 waves x 2 workgroups per CU (80 KB of LDS each)"),
     ("igemm_kernel<bf16_t, 144, 256, 1, 8, 6, 2>", 256, "image tiles: 8 waves, one workgroup per CU"),
     ("conv1_bwd_kernel<bf16_t, true, true,", 168, "__launch_bounds__(256, 3)"),
