@@ -988,11 +988,14 @@ int mtn_wgrad3_splits(int B, int H, int W, int N, int Cin, int dtype, int* slots
 
 // the kernel-row form serves 3x3 layers whose input has ONE 64-channel slab per tap tile anyway (Cin = 64:
 // wgrad_tile picks 128 x 64 there) and 128-wide outputs -- conv2 of the model
-static int g_wgrad_row3 = 1;     // debug key 18
+static int g_wgrad_row3 = 2;     // debug key 18 (0 off, 1: 64-channel inputs only, 2: every stride-2 3x3 layer too)
 void mtn_wgrad_set_row3(int on) { g_wgrad_row3 = on; }
 int mtn_wgrad_row3_ok(int dtype, int N, int Cin, int ksize, int stride) {
     (void)dtype;
-    return g_wgrad_row3 && g_wgrad_dma && ksize == 3 && Cin == 64 && N % 128 == 0 && !(stride == 1 && g_wgrad3);
+    // (round 5: also the wider stride-2 layers -- down1 / down2 -- as kernel-row tiles of 64-channel slabs: one dY tile for the three
+    //  taps of a kernel row instead of one per tap; down1 150 -> 134 us, down2 138 -> 135, step -0.03 ms.  Debug key 18 = 1: Cin = 64 only)
+    return g_wgrad_row3 && g_wgrad_dma && ksize == 3 && (Cin == 64 || (g_wgrad_row3 == 2 && stride == 2 && Cin % 64 == 0)) && N % 128 == 0 &&
+           !(stride == 1 && g_wgrad3);
 }
 int mtn_wgrad_row3_splits(int M, int N, int Cin, int dtype, int* rows_per_split) {
     const int bmr = dtype == MTN_BF16 ? 64 : 32;
