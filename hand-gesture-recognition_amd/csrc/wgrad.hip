@@ -803,12 +803,18 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
             }
         } else if constexpr (X3) {
             // one register set (a Frag3 is 8 registers: two sets of 11 would not leave room for the 18 accumulator quads)
-            MTN_UNROLL for (int j = 0; j < NSUB; ++j) {
-                Frag3 fy[2];
-                MTN_UNROLL for (int i = 0; i < 2; ++i) fy[i] = frag(rd, yoff[i][0] + j * SUB * RE, yoff[i][1] + j * SUB * RE, 0, 0);
-                MTN_UNROLL for (int t = 0; t < 9; ++t) {
-                    const Frag3 fx = frag(rd, xoff[t][0] + j * SUB * RE, xoff[t][1] + j * SUB * RE, 0, 0);
-                    MTN_UNROLL for (int i = 0; i < 2; ++i) acc[t][i] = Mma<T>::mma(fx, fy[i], acc[t][i]);
+            // (the sub-step loop is unrolled by two at most: with four unrolled sub-steps -- 128 slots per step -- hipcc hoists
+            //  fragment reads across them and spills 17 registers into the loop)
+            constexpr int UJ = NSUB > 2 ? 2 : NSUB;
+            _Pragma("clang loop unroll(disable)") for (int jj = 0; jj < NSUB / UJ; ++jj) {
+                const T* rj = rd + jj * (UJ * SUB * 64);
+                MTN_UNROLL for (int j = 0; j < UJ; ++j) {
+                    Frag3 fy[2];
+                    MTN_UNROLL for (int i = 0; i < 2; ++i) fy[i] = frag(rj, yoff[i][0] + j * SUB * RE, yoff[i][1] + j * SUB * RE, 0, 0);
+                    MTN_UNROLL for (int t = 0; t < 9; ++t) {
+                        const Frag3 fx = frag(rj, xoff[t][0] + j * SUB * RE, xoff[t][1] + j * SUB * RE, 0, 0);
+                        MTN_UNROLL for (int i = 0; i < 2; ++i) acc[t][i] = Mma<T>::mma(fx, fy[i], acc[t][i]);
+                    }
                 }
             }
         } else {
@@ -937,8 +943,11 @@ int launch_wgrad_row3(const WgradArgs& p, hipStream_t stream) {
     return mtn_check_launch("wgrad_row3");
 }
 
-static int g_wgrad3_ks256 = 1;   // debug key 29: 0 = 128 slots per step for every bf16 map (default: 256 for maps up to 48 wide)
-static int mtn_wgrad3_ks(int dtype, int W) { return dtype == MTN_BF16 ? ((g_wgrad3_ks256 && W <= 48) ? 256 : 128) : 64; }
+static int g_wgrad3_ks256 = 1;   // debug key 29: 0 = the narrow step for every map (default: 256 slots for bf16 maps up to 48 wide, 128 for split storage up to 24)
+static int mtn_wgrad3_ks(int dtype, int W) {
+    if (dtype == MTN_BF16) return (g_wgrad3_ks256 && W <= 48) ? 256 : 128;
+    return (dtype == MTN_F32X3 && g_wgrad3_ks256 && W <= 24) ? 128 : 64;    // split storage: 2 x 78 KB of stages for maps up to 24 wide
+}
 template <class T>
 int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
     constexpr int KS = Wg3<T>::KS, RPB = Wg3<T>::RPB;
@@ -950,6 +959,13 @@ int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
         if (mtn_wgrad3_ks(MTN_BF16, p.W) == 256) {
             MTN_REQUIRE(p.rows_per_split % 256 == 0, "wgrad3: %d slots per split for 256-slot steps", p.rows_per_split);
             MTN_LAUNCH((wgrad3_kernel<T, 256, 48>), dim3(tiles * p.splits), dim3(512), 0, stream, p);
+            return mtn_check_launch("wgrad3");
+        }
+    }
+    if constexpr (std::is_same<T, f32x3_t>::value) {
+        if (mtn_wgrad3_ks(MTN_F32X3, p.W) == 128) {
+            MTN_REQUIRE(p.rows_per_split % 128 == 0, "wgrad3: %d slots per split for 128-slot steps", p.rows_per_split);
+            MTN_LAUNCH((wgrad3_kernel<T, 128, 24>), dim3(tiles * p.splits), dim3(512), 0, stream, p);
             return mtn_check_launch("wgrad3");
         }
     }

@@ -341,7 +341,8 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  *          2: also K = 512); key 24 = channel-chunk order of bn_act_fwd; key 25 = bands per image of the pose-head
  *          backward (0 = by batch size); keys 26 / 27 = measured-and-rejected tail variants (experiments builds: profiles/r04_tail_ab.txt);
  *          key 28 = 0: f32 partial tiles in the split-K workspace of the bf16 mode (default: bf16 tiles, summed in f32);
- *          key 29 = 0: 128 slots per step in the 3x3 window weight gradient for every bf16 map (default: 256 for maps up to 48 wide);
+ *          key 29 = 0: the narrow step of the 3x3 window weight gradient for every map -- 128 slots bf16, 64 split storage
+ *                      (default: 256 for bf16 maps up to 48 wide, 128 for split-storage maps up to 24 wide);
  *          key 8 = 7 / 8: the 256x64 window tile of the 64-channel 3x3 layers whatever the row count / never.
  * Every key is refused (MTN_ERR_UNSUPPORTED, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
  * call into the library: the product path has no mutable configuration.
