@@ -410,6 +410,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const T* __restrict__ 
 }
 
 // ---- backward 2: dK, dV (sum over queries); LDS holds Q and dO of the head ------------------------
+// lse / delta of the head's queries sit in LDS behind the two operand tiles (read once per (query, key tile) in the loop) in every
+// mode: the longest sequence the kernels accept (608 rows) leaves 3.3 KB of the 160 KB for them in the 4-byte modes
 template <class T>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
@@ -419,7 +421,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
     const int NP = (N + 31) & ~31, nkt = (N + 15) / 16, nqp = NP / 32;
     T* sQ = reinterpret_cast<T*>(smem);
     T* sD = sQ + NP * PITCH;
-    constexpr bool kStageRows = sizeof(T) == 2;                 // fp32 mode reads lse / delta from global
     float* sL = reinterpret_cast<float*>(sD + NP * PITCH);      // lse[NP]
     float* sDl = sL + NP;                                       // delta[NP]
     const int bh = attn_bh(H), b = bh / H, h = bh - b * H;
@@ -437,11 +438,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
     };
     fetch(wid);
     stage_heads<T>(sQ, qkv, ld, h * HD, sD, dout, ldo, h * HD, row0, N, NP);
-    if (kStageRows)
-        for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-            sL[i] = i < N ? lse[(long)bh * N + i] * 1.4426950408889634f : 0.f;      // (in log2 units: one multiply per row, not per score)
-            sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
-        }
+    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        sL[i] = i < N ? lse[(long)bh * N + i] * 1.4426950408889634f : 0.f;          // (in log2 units: one multiply per row, not per score)
+        sDl[i] = i < N ? delta[(long)bh * N + i] : 0.f;
+    }
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;
     for (int kt = wid; kt < nkt; kt += nw) {
@@ -463,8 +463,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const T* __restrict__
                 //  dV = P^T dO and dK = dS^T Q; padded key lanes compute columns that are never stored)
                 MTN_UNROLL for (int r = 0; r < 4; ++r) {
                     const int q = qb + 4 * g + r;
-                    const float lq = kStageRows ? sL[q] : (q < N ? lse[(long)bh * N + q] * 1.4426950408889634f : 0.f);
-                    const float dq = kStageRows ? sDl[q] : (q < N ? delta[(long)bh * N + q] : 0.f);
+                    const float lq = sL[q], dq = sDl[q];
                     const float pv = exp2f_(fmaf(s[r], c2, -lq));
                     p[hf][r] = pv;
                     ds[hf][r] = pv * (dp[r] - dq);           // (scale: once on dK below)
@@ -529,7 +528,10 @@ int attn_bwd_t(const AttnArgs& a, hipStream_t stream) {
 #undef MTN_ATTN_DQ
     int rc = mtn_check_launch("attn_bwd_dq");
     if (rc) return rc;
-    const size_t lds2 = lds + (sizeof(T) == 2 ? 2 * (size_t)NP * sizeof(float) : 0);
+    // (round 5: the 4-byte modes stage lse / delta too -- the split-storage kernel spent 123 us per layer at 145 tokens against
+    //  33 us in bf16, most of it waiting on those eight global loads per query pair: bf16x3 step -0.20 ms, -0.48 ms at 577 tokens)
+    const size_t lds2 = lds + 2 * (size_t)NP * sizeof(float);
+    MTN_REQUIRE(lds2 <= 160 * 1024, "attention backward: %d rows do not fit the LDS", NP);
     set_max_lds(attn_bwd_dkv_kernel<T>, lds2);
     MTN_LAUNCH((attn_bwd_dkv_kernel<T>), grid, block, lds2, stream, (const T*)a.qkv, (const T*)a.dout, a.lse, a.delta,
                (T*)a.dqkv, a.N, a.H, a.scale);

@@ -638,29 +638,58 @@ __global__ __launch_bounds__(256) void pose_fwd_mma_kernel(const T* __restrict__
 // The map width is a template parameter: the x loop is fully unrolled, so the y-mixed row lives in
 // registers and every x tap index / weight is a literal (a first version read them from LDS tables
 // in a rolled loop: three dependent LDS round trips per output element, 10x slower).
+// Split mode (T = f32s_t: plain f32 tokens, head products as three bf16 MFMAs): the weight and relu(u) tiles sit in LDS as
+// a hi and a lo bf16 PLANE each, split once when they are written (round 5).  The first version kept f32 tiles and split
+// every fragment as it was read -- ~28 VALU operations per fragment per K-step, the weights again for every output row:
+// VALU-bound at 3x the bf16 kernel's time.  The planes hold the same bits the read-time split produced.  Weight rows beyond
+// the J joints share ONE zero row (row J), which brings the workgroup under 80 KB: two per CU instead of one.
 template <class T, int WT>
 __global__ __launch_bounds__(256) void pose_fwd_row_kernel(const T* __restrict__ tok, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ hm, int h,
                                                            int J, int rows_per_band) {
+    constexpr bool SP = std::is_same<T, f32s_t>::value;
     constexpr int PW = DIM + 16 / (int)sizeof(T);
+    constexpr int PB = DIM + 8;                                  // pitch of a bf16 plane (split mode)
     constexpr int KI = Mma<T>::KI;
     constexpr int w = WT, OW = 4 * WT, OWM = (OW + 15) & ~15;
     MTN_DYN_SMEM(smem);
     const int hw = h * w, OH = 4 * h;
     T* sW = reinterpret_cast<T*>(smem);                          // [32][PW]
     T* sR = sW + 32 * PW;                                        // [OWM][PW]
+    const int WR = J < 32 ? J + 1 : 32;                          // split mode: weight rows held (row J = zeros)
+    bf16_t* pWh = reinterpret_cast<bf16_t*>(smem);               // [WR][PB] hi, lo
+    bf16_t* pWl = pWh + WR * PB;
+    bf16_t* pRh = pWl + WR * PB;                                 // [OWM][PB] hi, lo
+    bf16_t* pRl = pRh + OWM * PB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.y;
     const int r_begin = blockIdx.x * rows_per_band;
     int r_end = r_begin + rows_per_band;
     if (r_end > OH) r_end = OH;
-    for (int i = tid; i < 32 * (DIM / 4); i += 256) {
-        const int j = i / (DIM / 4), c = (i - j * (DIM / 4)) * 4;
-        f32x4_t v = zero4();
-        if (j < J) v = *reinterpret_cast<const f32x4_t*>(W + j * DIM + c);
-        store4<T>(sW + j * PW + c, v);
+    if constexpr (SP) {
+        for (int i = tid; i < WR * (DIM / 4); i += 256) {
+            const int j = i / (DIM / 4), c = (i - j * (DIM / 4)) * 4;
+            f32x4_t v = zero4();
+            if (j < J) v = *reinterpret_cast<const f32x4_t*>(W + j * DIM + c);
+            MTN_UNROLL for (int e = 0; e < 4; ++e) {
+                const bf16_t hi = f2bf(v[e]);
+                pWh[j * PB + c + e] = hi;
+                pWl[j * PB + c + e] = f2bf(v[e] - bf2f(hi));
+            }
+        }
+        for (int i = tid; i < (OWM - OW) * DIM; i += 256) {                                                       // M padding rows
+            pRh[(OW + i / DIM) * PB + (i % DIM)] = f2bf(0.f);
+            pRl[(OW + i / DIM) * PB + (i % DIM)] = f2bf(0.f);
+        }
+    } else {
+        for (int i = tid; i < 32 * (DIM / 4); i += 256) {
+            const int j = i / (DIM / 4), c = (i - j * (DIM / 4)) * 4;
+            f32x4_t v = zero4();
+            if (j < J) v = *reinterpret_cast<const f32x4_t*>(W + j * DIM + c);
+            store4<T>(sW + j * PW + c, v);
+        }
+        for (int i = tid; i < (OWM - OW) * DIM; i += 256) sR[(OW + i / DIM) * PW + (i % DIM)] = from_f<T>(0.f);   // M padding rows
     }
-    for (int i = tid; i < (OWM - OW) * DIM; i += 256) sR[(OW + i / DIM) * PW + (i % DIM)] = from_f<T>(0.f);   // M padding rows
     const T* base = tok + ((long)b * (hw + 1) + 1) * DIM + tid;   // this thread's channel
     const int frow = lane & 15, fk = (lane >> 4) * (KI / 4);
     const int nfr = (OWM / 16) * 2;                               // head fragments (pixels x joint halves)
@@ -682,14 +711,34 @@ __global__ __launch_bounds__(256) void pose_fwd_row_kernel(const T* __restrict__
         MTN_UNROLL for (int ox = 0; ox < OW; ++ox) {
             const Lerp lx = lerp_coord(ox, WT, OW);               // literals after unrolling
             const float u = (1.f - lx.w1) * ya[lx.i0] + lx.w1 * ya[lx.i1];
-            sR[ox * PW + tid] = from_f<T>(u > 0.f ? u : 0.f);
+            const float r = u > 0.f ? u : 0.f;
+            if constexpr (SP) {
+                const bf16_t hi = f2bf(r);
+                pRh[ox * PB + tid] = hi;
+                pRl[ox * PB + tid] = f2bf(r - bf2f(hi));
+            } else {
+                sR[ox * PW + tid] = from_f<T>(r);
+            }
         }
         __syncthreads();
         for (int f = wid; f < nfr; f += 4) {                      // hm[j][px] : the weight fragment is the row operand
             const int pf = f >> 1, jf = f & 1;
             f32x4_t acc = zero4();
-            MTN_UNROLL for (int k0 = 0; k0 < DIM; k0 += KI)
-                acc = Mma<T>::mma(Mma<T>::load(sW + (jf * 16 + frow) * PW + k0 + fk), Mma<T>::load(sR + (pf * 16 + frow) * PW + k0 + fk), acc);
+            if constexpr (SP) {
+                const int wr = jf * 16 + frow < WR ? jf * 16 + frow : WR - 1;
+                const bf16_t* aw = pWh + wr * PB + fk;
+                const bf16_t* ar = pRh + (pf * 16 + frow) * PB + fk;
+                const int lo_w = WR * PB, lo_r = OWM * PB;        // hi plane -> lo plane
+                MTN_UNROLL for (int k0 = 0; k0 < DIM; k0 += KI) {
+                    Frag3 fa, fb;
+                    fa.hi = load_bf16x8(aw + k0); fa.lo = load_bf16x8(aw + lo_w + k0);
+                    fb.hi = load_bf16x8(ar + k0); fb.lo = load_bf16x8(ar + lo_r + k0);
+                    acc = Mma<f32x3_t>::mma(fa, fb, acc);
+                }
+            } else {
+                MTN_UNROLL for (int k0 = 0; k0 < DIM; k0 += KI)
+                    acc = Mma<T>::mma(Mma<T>::load(sW + (jf * 16 + frow) * PW + k0 + fk), Mma<T>::load(sR + (pf * 16 + frow) * PW + k0 + fk), acc);
+            }
             const int ox = pf * 16 + (lane & 15);
             MTN_UNROLL for (int r = 0; r < 4; ++r) {
                 const int j = jf * 16 + 4 * (lane >> 4) + r;
@@ -952,8 +1001,9 @@ static void pose_bwd_row_dispatch(int w, int B, size_t lds, hipStream_t stream, 
 }
 
 template <class T>
-static size_t pose_fwd_row_lds(int w) {
+static size_t pose_fwd_row_lds(int w, int J) {
     const int OW = 4 * w, OWM = (OW + 15) & ~15;
+    if (std::is_same<T, f32s_t>::value) return (size_t)((J < 32 ? J + 1 : 32) + OWM) * 2 * (DIM + 8) * sizeof(bf16_t);   // hi + lo planes
     return (size_t)(32 + OWM) * (DIM * sizeof(T) + 16);
 }
 // instantiated map widths: 12 (192^2 images), 24 (384^2), 6 (96^2; also the CPU kernel-logic tests)
@@ -1077,9 +1127,10 @@ int mtn_pose_fwd_run(const void* tok, const float* W, const float* bias, float* 
     {
         const bool x3 = dtype == MTN_F32X3;      // plain f32 tokens, head products as split-bf16 MFMAs (f32s_t, mtn_types.h)
         if (x3) dtype = MTN_F32;
-        const size_t lds = dtype == MTN_BF16 ? pose_fwd_row_lds<bf16_t>(w) : pose_fwd_row_lds<float>(w);
+        const size_t lds = dtype == MTN_BF16 ? pose_fwd_row_lds<bf16_t>(w, J) : (x3 ? pose_fwd_row_lds<f32s_t>(w, J) : pose_fwd_row_lds<float>(w, J));
         if (g_pose_row && pose_row_width(w) && lds <= 160 * 1024) {   // row-streaming kernel: all 256 channels per workgroup
-            int bands = mtn_cdiv(768, B);                 // >= 768 workgroups (three per CU at B = 256: 42 KB of LDS each)
+            // >= 768 workgroups (three per CU at B = 256: 42 KB of LDS each); split mode: 512 (two per CU, 74 KB each)
+            int bands = mtn_cdiv(x3 ? 512 : 768, B);
             if (bands > OH) bands = OH;
             const int rpb = mtn_cdiv(OH, bands);
             const dim3 grid(mtn_cdiv(OH, rpb), B);

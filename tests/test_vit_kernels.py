@@ -142,7 +142,7 @@ def _attn_ref(qkv, B, N, H, D):
 
 
 @pytest.mark.parametrize("dtype", GEMM_DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 5, 2), (1, 37, 8), (8, 5, 2), (1, 145, 2), (1, 200, 1), (1, 577, 1)])
+@pytest.mark.parametrize("cfg", [(2, 5, 2), (1, 37, 8), (8, 5, 2), (1, 145, 2), (1, 200, 1), (1, 577, 1), (1, 608, 1)])
 def test_attention_fwd_bwd(be, dtype, cfg, request):
     B, N, H = cfg
     D = 32
