@@ -252,6 +252,10 @@ def validation(a, dev, oracle_ref):
         import mtn_oracle as O
         sd, batch, (oc, oh, oa), (ot, _, _), og = oracle_ref
         errs = {}
+        # the same pass in float64 (a few seconds of CPU): the truth both the reference's fp32 arithmetic and ours are measured from
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+        _, _, tg = O.forward_backward(sd64, tuple(t.double() if t.dtype.is_floating_point else t for t in batch))
+        truth = {"reference_fp32": float(f"{max(_rel(og[k], tg[k]) for k in og):.2e}")}
         for mode in ("bf16", "bf16x3", "fp32"):
             m = MultiTaskNet(21, 19, [192, 192], compute_dtype=_DT[mode])
             m.load_state_dict(sd, strict=True)
@@ -265,12 +269,17 @@ def validation(a, dev, oracle_ref):
                           "attnmap": float(f"{_rel(at, oa):.2e}"),
                           "total_loss": float(f"{abs(float(tot.detach()) - float(ot)) / abs(float(ot)):.2e}"),
                           "worst_param_grad": float(f"{max(_rel(p.grad, og[k]) for k, p in m.named_parameters()):.2e}")}
+            truth[mode] = float(f"{max(_rel(p.grad, tg[k]) for k, p in m.named_parameters()):.2e}")
             del m
         out["errors_vs_oracle_config1_b4"] = errs
         out["meets_1e-3_on_outputs"] = {m: bool(max(e["logits"], e["heatmaps"], e["attnmap"], e["total_loss"]) < 1e-3) for m, e in errs.items()}
         # (parameter gradients at B=4 are sums over few pixels of cancelling terms: the reference's own fp32 arithmetic is
         #  8.2e-4 from a float64 run there -- DESIGN.md section 2b; the split-bf16 mode is gated at 2.5e-3 for this size)
         out["meets_1e-3_on_grads"] = {m: bool(e["worst_param_grad"] < 1e-3) for m, e in errs.items()}
+        # worst parameter gradient against the float64 evaluation: the reference's fp32 arithmetic is itself ~8e-4 away at B=4, so the
+        # figure against the fp32 oracle above moves between ~0.9e-3 and ~1.6e-3 with the summation order of either side; the 1e-3
+        # gradient gates run at the full batch against a float64 truth (tests/test_full_size_parity.py: bf16x3 7.5e-4 at B=256)
+        out["worst_param_grad_vs_float64_config1_b4"] = truth
     return out
 
 
