@@ -26,7 +26,7 @@ int mtn_check_launch(const char* what) {
 extern "C" {
 
 const char* mtn_last_error(void) { return g_err; }
-int mtn_abi_version(void) { return 6; }
+int mtn_abi_version(void) { return 7; }
 
 int mtn_conv_stats_tiles(int M, int Cout, int K) { return mtn_igemm_tiles_m(M, Cout, K); }
 
@@ -218,6 +218,54 @@ int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
     // the M rows as ONE image of width M: the kernels' pixel walk then never crosses an image
     // boundary (as M images of 1x1 it would, on every row of every step)
     return mtn_conv_wgrad(x, ldx, dy, lddy, dw, workspace, ws_bytes, dtype, 1, 1, M, K, N, 1, 1, stream);
+}
+
+// The Linear weight gradients of a whole backward pass in one launch + one split sum (wgrad.hip): `count` problems
+// dw_i[N_i][K_i] = dy_i[M][N_i]^T x_i[M][K_i] over the same M rows.  Groups the kernel cannot take in one launch (a side that
+// is no multiple of 128, more than MTN_WGRAD_GROUP_MAX problems) run as `count` mtn_linear_wgrad calls on the same workspace.
+size_t mtn_linear_wgrad_group_workspace_bytes(int dtype, int M, const mtn_wgrad_item* items, int count) {
+    if (!items || count <= 0 || M <= 0) return 0;
+    size_t need = 0;
+    for (int i = 0; i < count; ++i) {
+        const size_t b = mtn_linear_wgrad_workspace_bytes(dtype, M, items[i].N, items[i].K);
+        if (!b) return 0;
+        need = b > need ? b : need;
+    }
+    for (int i0 = 0; i0 < count; i0 += MTN_WGRAD_GROUP_MAX) {
+        const int n = count - i0 < MTN_WGRAD_GROUP_MAX ? count - i0 : MTN_WGRAD_GROUP_MAX;
+        int Ns[MTN_WGRAD_GROUP_MAX], Ks[MTN_WGRAD_GROUP_MAX];
+        for (int i = 0; i < n; ++i) { Ns[i] = items[i0 + i].N; Ks[i] = items[i0 + i].K; }
+        const size_t b = mtn_wgrad_group_bytes(dtype, M, Ns, Ks, n);
+        need = b > need ? b : need;
+    }
+    return need;
+}
+
+int mtn_linear_wgrad_group(const mtn_wgrad_item* items, int count, int M, void* workspace, size_t ws_bytes, int dtype, void* stream) {
+    MTN_REQUIRE(items && count > 0 && M > 0 && workspace, "linear_wgrad_group: bad arguments (count=%d, M=%d)", count, M);
+    for (int i0 = 0; i0 < count; i0 += MTN_WGRAD_GROUP_MAX) {
+        const int n = count - i0 < MTN_WGRAD_GROUP_MAX ? count - i0 : MTN_WGRAD_GROUP_MAX;
+        int Ns[MTN_WGRAD_GROUP_MAX], Ks[MTN_WGRAD_GROUP_MAX], rps = 0;
+        for (int i = 0; i < n; ++i) { Ns[i] = items[i0 + i].N; Ks[i] = items[i0 + i].K; }
+        if (mtn_wgrad_group_plan(dtype, M, Ns, Ks, n, &rps) > 0) {
+            WgradGroupArgs g{};
+            g.count = n;
+            for (int i = 0; i < n; ++i) {
+                const mtn_wgrad_item& it = items[i0 + i];
+                g.item[i].dY = it.dy; g.item[i].lddy = it.lddy; g.item[i].X = it.x; g.item[i].ldx = it.ldx;
+                g.item[i].dW = it.dw; g.item[i].N = it.N; g.item[i].K = it.K;
+            }
+            const int rc = mtn_wgrad_group_run(g, dtype, M, workspace, ws_bytes, (hipStream_t)stream);
+            if (rc) return rc;
+            continue;
+        }
+        for (int i = 0; i < n; ++i) {
+            const mtn_wgrad_item& it = items[i0 + i];
+            const int rc = mtn_linear_wgrad(it.x, it.ldx, it.dy, it.lddy, it.dw, workspace, ws_bytes, dtype, M, it.N, it.K, stream);
+            if (rc) return rc;
+        }
+    }
+    return MTN_OK;
 }
 
 int mtn_conv1_stats_tiles(int B, int H, int W) { return mtn_conv1_tiles((long)B * (H / 2) * (W / 2)); }
@@ -487,6 +535,7 @@ int mtn_debug_set(int key, int value) {
     if (key == 25) { mtn_pose_set_bands(value); return MTN_OK; }
     if (key == 28) { mtn_wgrad_set_slab_bf16(value); return MTN_OK; }
     if (key == 29) { mtn_wgrad_set_ks256(value); return MTN_OK; }
+    if (key == 30) { mtn_wgrad_set_group(value); return MTN_OK; }
     if (key == 26 || key == 27) {
 #ifdef MTN_EXPERIMENTS
         if (key == 26) mtn_bn_set_ticket(value);

@@ -80,6 +80,18 @@ struct WgradArgs {
     unsigned magic_ow, magic_oh;  // filled by mtn_wgrad_run: multiply-high divisors of the pixel walk
     int slab_bf16;                // filled by mtn_wgrad_run: the partial tiles are stored as bf16 (bf16 mode only)
 };
+// several pointwise problems (same row count) in one launch: wgrad.hip, wgrad_dma2_group_kernel
+constexpr int MTN_WGRAD_GROUP_MAX = 16;
+struct WgradGroupArgs {
+    int count;
+    int first[MTN_WGRAD_GROUP_MAX + 1];       // workgroup ranges of the problems (multiples of 8)
+    int rfirst[MTN_WGRAD_GROUP_MAX + 1];      // block ranges of the grouped split sum
+    WgradArgs item[MTN_WGRAD_GROUP_MAX];
+};
+int mtn_wgrad_group_plan(int dtype, int M, const int* N, const int* K, int count, int* rows_per_split);
+size_t mtn_wgrad_group_bytes(int dtype, int M, const int* N, const int* K, int count);
+int mtn_wgrad_group_run(WgradGroupArgs& g, int dtype, int M, void* workspace, size_t ws_bytes, hipStream_t stream);
+void mtn_wgrad_set_group(int on);
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);
 void mtn_wgrad_set_tr16(int on);

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
     const int tiles = tiles_n * (p.K / BC);
     int tile, split;
     {
-        const int L = blockIdx.x;
+        const int L = blockIdx.x, nwg = gridDim.x;
         if (p.splits % 8 == 0 && tiles <= 24) {
             const int xcd = L & 7, j = L >> 3;
             split = (j / tiles) * 8 + xcd;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
             // many tiles per split: give each XCD group (id % 8) a contiguous range of the
             // (split, tile) order, so the tiles of one split -- which all stream the same rows of
             // dY and X -- share one L2 instead of spreading over all eight
-            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+            const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
             const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
             split = lin / tiles;
             tile = lin % tiles;
@@ -376,8 +376,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma_kernel(WgradArgs p) {
 // in the ISA of the one-array form: a workgroup then never overlaps its own DMA with its own MFMAs).  That overlap measured
 // slower in bf16 (round 2) AND in the split-bf16 mode (round 3: 22.1 vs 21.25 ms per step): the co-resident workgroups
 // already cover each other, and DMA in flight contends with the fragment reads.  Kept behind debug key 20.
-template <class T, int BN, int BC, int WGM, int WGN, bool SEP = false>
-__global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) {
+// (the body takes the workgroup's index in ITS problem's grid and that grid's size: wgrad_dma2_group_kernel below runs several
+//  problems in one launch)
+template <class T, int BN, int BC, int WGM, int WGN, bool SEP>
+__device__ __forceinline__ void wgrad_dma2_body(const WgradArgs& p, const int L, const int nwg) {
     constexpr int NW = WGM * WGN;
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int BMR = 128 / (int)sizeof(T);
@@ -402,7 +404,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) 
     const int tiles = tiles_n * (p.K / BC);
     int tile, split;
     {
-        const int L = blockIdx.x;
         if (p.splits % 8 == 0 && tiles <= 24) {
             const int xcd = L & 7, j = L >> 3;
             split = (j / tiles) * 8 + xcd;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) 
             // many tiles per split: give each XCD group (id % 8) a contiguous range of the
             // (split, tile) order, so the tiles of one split -- which all stream the same rows of
             // dY and X -- share one L2 instead of spreading over all eight
-            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+            const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
             const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
             split = lin / tiles;
             tile = lin % tiles;
@@ -496,6 +497,31 @@ __global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) 
                 const int k = kcol0 + wn * WN + j * 16 + 4 * (lane >> 4);
                 slab_store(p, split, n, k, acc[i][j]);
             }
+}
+
+template <class T, int BN, int BC, int WGM, int WGN, bool SEP = false>
+__global__ __launch_bounds__(WGM* WGN * 64) void wgrad_dma2_kernel(WgradArgs p) {
+    wgrad_dma2_body<T, BN, BC, WGM, WGN, SEP>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- several pointwise problems in ONE launch (round 5) ----------------------------------------------------------------
+// The sixteen Linear weight gradients of the ViT are 37,120-row reductions: as sixteen launches each fills the chip's 512
+// workgroup slots with 40 .. 120 splits of ~10 K-steps -- prologue, ring fill and a 64 KB partial tile per workgroup for
+// ten steps of work (410 TFLOP/s, and 31 MB of slab per launch written and read back) where the same kernel reaches
+// 650 TFLOP/s on a long reduction axis (tools/probes/linear_wgrad_scaling.py).  Nothing downstream needs a weight gradient
+// before the optimizer, so the plan defers them and runs all of them here: workgroup L belongs to the problem whose block
+// range [first[i], first[i+1]) holds it (ranges are multiples of 8, so L & 7 is still the XCD inside the problem's grid);
+// 128 tiles x 4 splits of 145 steps each, 33 MB of slab in all, one grouped reduce.
+template <class T>
+__global__ __launch_bounds__(512) void wgrad_dma2_group_kernel(WgradGroupArgs g) {
+    const int L = (int)blockIdx.x;
+    int prob = 0;
+    for (int i = 1; i < g.count; ++i) prob += L >= g.first[i] ? 1 : 0;
+    const WgradArgs p = g.item[prob];
+    const int l = L - g.first[prob];
+    const int nwg = (p.N / 128) * (p.K / 128) * p.splits;      // (the range is padded to a multiple of 8 workgroups)
+    if (l >= nwg) return;
+    wgrad_dma2_body<T, 128, 128, 4, 2, false>(p, l, nwg);
 }
 
 
@@ -855,12 +881,12 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
 // thread (the first version read 4 bytes per lane with one load in flight: 3 TB/s on a slab that sits in
 // the memory-side cache); the 8 lanes are summed in a fixed order -> deterministic.
 template <class PT>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const PT* __restrict__ partial, float* __restrict__ dw,
-                                                           int splits, int N, int K, int Cin, int taps) {
+__device__ __forceinline__ void wgrad_reduce_body(const PT* __restrict__ partial, float* __restrict__ dw, int splits, int N, int K,
+                                                  int Cin, int taps, const int block) {
     __shared__ f32x4_t red[8][32];
     const int sl = threadIdx.x >> 5, el = threadIdx.x & 31;
     const long total = (long)N * K;                        // multiple of 4 (host-checked)
-    const long idx = ((long)blockIdx.x * 32 + el) * 4;
+    const long idx = ((long)block * 32 + el) * 4;
     f32x4_t s = zero4();
     if (idx < total) {
         const PT* src = partial + idx;
@@ -880,6 +906,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const PT* __restrict_
         const int tap = k / Cin, ci = k - tap * Cin;       // the 4 elements share n and tap (Cin % 4 == 0)
         MTN_UNROLL for (int e = 0; e < 4; ++e) dw[((long)n * Cin + ci + e) * taps + tap] = t[e];
     }
+}
+template <class PT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const PT* __restrict__ partial, float* __restrict__ dw,
+                                                           int splits, int N, int K, int Cin, int taps) {
+    wgrad_reduce_body<PT>(partial, dw, splits, N, K, Cin, taps, (int)blockIdx.x);
+}
+// the split sums of every problem of a grouped launch (block ranges rfirst[])
+template <class PT>
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradGroupArgs g) {
+    const int L = (int)blockIdx.x;
+    int prob = 0;
+    for (int i = 1; i < g.count; ++i) prob += L >= g.rfirst[i] ? 1 : 0;
+    const WgradArgs p = g.item[prob];
+    wgrad_reduce_body<PT>(reinterpret_cast<const PT*>(p.partial), p.dW, p.splits, p.N, p.K, p.Cin, 1, L - g.rfirst[prob]);
 }
 
 template <class T, int BN, int BC, int WGM, int WGN, bool TR>
@@ -1178,4 +1218,119 @@ int mtn_wgrad_run(const WgradArgs& p0, int dtype, hipStream_t stream) {
         MTN_LAUNCH(wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)p.partial, p.dW, p.splits, p.N, p.K,
                    p.Cin, p.KH * p.KW);
     return mtn_check_launch("wgrad_reduce");
+}
+
+
+// ---- grouped pointwise weight gradients (wgrad_dma2_group_kernel) ----------------------------------------------------------
+static int g_wgrad_group = 1;    // debug key 30: 0 = mtn_linear_wgrad_group runs its problems one launch each
+void mtn_wgrad_set_group(int on) { g_wgrad_group = on ? 1 : 0; }
+
+// Split of the row axis shared by the `count` problems [M][N_i] x [M][K_i] of one grouped launch (0: not groupable --
+// more than MTN_WGRAD_GROUP_MAX problems, or a side that is no multiple of the 128 x 128 tile): all tiles of all problems
+// x splits fill the 512 workgroup slots of the 8-wave tile once
+int mtn_wgrad_group_plan(int dtype, int M, const int* N, const int* K, int count, int* rows_per_split) {
+    if (!g_wgrad_group || count < 2 || count > MTN_WGRAD_GROUP_MAX || M <= 0) return 0;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        if (N[i] <= 0 || K[i] <= 0 || N[i] % 128 || K[i] % 128) return 0;
+        tiles += (long)(N[i] / 128) * (K[i] / 128);
+    }
+    const int bmr = dtype == MTN_BF16 ? 64 : 32;
+    const long max_splits = ((long)M + bmr - 1) / bmr;
+    long splits;
+    if (g_wgrad_slots > 0) {                                  // (debug key 10: a slot budget instead of the search below)
+        splits = g_wgrad_slots / tiles;
+        if (splits < 1) splits = 1;
+    } else {
+        // The launch runs in rounds of 512 workgroups (two per CU); every problem's range is padded to a multiple of 8, and a
+        // workgroup costs its K-steps plus ~16 steps' worth of prologue, ring fill and partial-tile store.  Pick the split count
+        // with the least rounds x (steps + 16): at 37,120 rows and 96 tiles that is 10 splits (960 workgroups, two full rounds:
+        // 209 us) -- 5 splits pad to 544 workgroups, a second round of 32 (318 us); tools/probes/linear_wgrad_group_probe.py
+        long best = 0;
+        splits = 1;
+        for (long sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
+            long blocks = 0;
+            for (int i = 0; i < count; ++i) blocks += ((long)(N[i] / 128) * (K[i] / 128) * sp + 7) / 8 * 8;
+            const long rows = (((long)M + sp - 1) / sp + bmr - 1) / bmr * bmr;
+            const long cost = ((blocks + 511) / 512) * (rows / bmr + 16);
+            if (best == 0 || cost < best) { best = cost; splits = sp; }
+        }
+    }
+    if (splits > max_splits) splits = max_splits;
+    long rps = (M + splits - 1) / splits;
+    rps = (rps + bmr - 1) / bmr * bmr;
+    *rows_per_split = (int)rps;
+    return (int)((M + rps - 1) / rps);
+}
+
+// g.item[i]: dY / lddy / X / ldx / dW / N / K (= Cin) filled by the caller; everything else here
+int mtn_wgrad_group_run(WgradGroupArgs& g, int dtype, int M, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "wgrad group: bad dtype %d", dtype);
+    MTN_REQUIRE(g.count >= 2 && g.count <= MTN_WGRAD_GROUP_MAX, "wgrad group: %d problems", g.count);
+    int Ns[MTN_WGRAD_GROUP_MAX], Ks[MTN_WGRAD_GROUP_MAX], rps = 0;
+    for (int i = 0; i < g.count; ++i) { Ns[i] = g.item[i].N; Ks[i] = g.item[i].K; }
+    const int splits = mtn_wgrad_group_plan(dtype, M, Ns, Ks, g.count, &rps);
+    MTN_REQUIRE(splits > 0, "wgrad group: the problems do not share the 128 x 128 tile");
+    const size_t esz = dtype == MTN_BF16 ? 2 : 4;
+    const int slab_bf16 = (dtype == MTN_BF16 && g_wgrad_slab_bf16) ? 1 : 0;
+    size_t off = 0;
+    int blocks = 0, rblocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+        WgradArgs& p = g.item[i];
+        MTN_REQUIRE(p.dY && p.X && p.dW, "wgrad group: null operand in problem %d", i);
+        MTN_REQUIRE((((uintptr_t)p.dY | (uintptr_t)p.X) % 16) == 0 && p.lddy % 8 == 0 && p.ldx % 8 == 0, "wgrad group: operands must be 16-byte aligned");
+        MTN_REQUIRE(dtype != MTN_F32X3 || (p.lddy % 32 == 0 && p.ldx % 32 == 0), "wgrad group: split storage needs row pitches that are multiples of 32");
+        MTN_REQUIRE(p.lddy >= p.N && p.ldx >= p.K, "wgrad group: row pitch below the row length in problem %d", i);
+        MTN_REQUIRE((long)M * p.lddy < (1L << 30) && (long)M * p.ldx < (1L << 30), "wgrad group: tensor too large for 32-bit byte offsets");
+        p.B = 1; p.H = 1; p.W = M; p.OH = 1; p.OW = M; p.Cin = p.K; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
+        p.M = M; p.splits = splits; p.rows_per_split = rps; p.win = 0;
+        p.magic_ow = 0; p.magic_oh = 0;
+        p.y_bytes = (unsigned)((((size_t)M - 1) * p.lddy + p.N) * esz);
+        p.x_bytes = (unsigned)((((size_t)M - 1) * p.ldx + p.K) * esz);
+        p.slab_bf16 = slab_bf16;
+        p.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
+        off += ((size_t)splits * p.N * p.K * (slab_bf16 ? 2 : 4) + 255) / 256 * 256;
+        g.first[i] = blocks;
+        blocks += ((p.N / 128) * (p.K / 128) * splits + 7) / 8 * 8;
+        g.rfirst[i] = rblocks;
+        rblocks += (int)(((long)p.N * p.K / 4 + 31) / 32);
+    }
+    g.first[g.count] = blocks;
+    g.rfirst[g.count] = rblocks;
+    MTN_REQUIRE(off <= ws_bytes, "wgrad group: workspace too small (%zu bytes, %zu needed)", ws_bytes, off);
+    constexpr size_t lds = 2 * 128 * (128 + 128);             // two stages of [BMR][128 + 128] T: BMR * sizeof(T) = 128
+#ifndef MTN_EMU
+    static MtnLdsAttr attr_b, attr_x, attr_f;
+#endif
+    if (dtype == MTN_BF16) {
+#ifndef MTN_EMU
+        mtn_set_max_lds(attr_b, &wgrad_dma2_group_kernel<bf16_t>, lds);
+#endif
+        MTN_LAUNCH(wgrad_dma2_group_kernel<bf16_t>, dim3(blocks), dim3(512), lds, stream, g);
+    } else if (dtype == MTN_F32X3) {
+#ifndef MTN_EMU
+        mtn_set_max_lds(attr_x, &wgrad_dma2_group_kernel<f32x3_t>, lds);
+#endif
+        MTN_LAUNCH(wgrad_dma2_group_kernel<f32x3_t>, dim3(blocks), dim3(512), lds, stream, g);
+    } else {
+#ifndef MTN_EMU
+        mtn_set_max_lds(attr_f, &wgrad_dma2_group_kernel<float>, lds);
+#endif
+        MTN_LAUNCH(wgrad_dma2_group_kernel<float>, dim3(blocks), dim3(512), lds, stream, g);
+    }
+    int rc = mtn_check_launch("wgrad_dma2_group");
+    if (rc) return rc;
+    if (slab_bf16) MTN_LAUNCH(wgrad_reduce_group_kernel<bf16_t>, dim3(rblocks), dim3(256), 0, stream, g);
+    else MTN_LAUNCH(wgrad_reduce_group_kernel<float>, dim3(rblocks), dim3(256), 0, stream, g);
+    return mtn_check_launch("wgrad_reduce_group");
+}
+
+// bytes of the slabs of a grouped launch (0: not groupable)
+size_t mtn_wgrad_group_bytes(int dtype, int M, const int* N, const int* K, int count) {
+    int rps = 0;
+    const int splits = mtn_wgrad_group_plan(dtype, M, N, K, count, &rps);
+    if (!splits) return 0;
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) off += ((size_t)splits * N[i] * K[i] * 4 + 255) / 256 * 256;
+    return off;
 }

@@ -69,6 +69,9 @@ class Engine:
         self.defer_leaf_sums = os.environ.get("MTN_DEFER_LEAF_SUMS", "1") != "0"
         # the token assembly in the projection's epilogue (MTN_FUSE_TOKENS=0: projection, then the tokens_fwd launch)
         self.fuse_tokens = os.environ.get("MTN_FUSE_TOKENS", "1") != "0"
+        # the sixteen Linear weight gradients of the ViT as ONE grouped launch at the end of its backward (mtn_linear_wgrad_group):
+        # their output gradients then live in per-layer buffers instead of the shared temporaries (MTN_GROUP_WGRAD=0: one launch each)
+        self.group_wgrad = os.environ.get("MTN_GROUP_WGRAD", "1") != "0"
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -212,6 +215,12 @@ class Engine:
         Mt = B * self.N
         for n_out, k_in in ((768, 256), (256, 256)):
             max_ws = max(max_ws, self.o.linear_wgrad_workspace_bytes(self.dt, Mt, n_out, k_in))
+        if self.group_wgrad:
+            shapes = []
+            for L in self.layers:
+                at, ff = L["attn"], L["ff"]
+                shapes += [tuple(w.shape) for w in (ff.net[4].weight, ff.net[1].weight, at.to_out.weight, at.to_qkv.weight)]
+            max_ws = max(max_ws, self.o.linear_wgrad_group_workspace_bytes(self.dt, shapes, Mt))
         self.dyraw = self._new((max_dy,))
         self.bn_part = self._f32(max_part)
         self.wgrad_ws = self._f32(max_ws // 4 + 4)
@@ -249,6 +258,13 @@ class Engine:
             L["a"], L["hg"] = self._new((Mt, D)), self._new((Mt, D))
         self.t_a, self.t_b = self._new((Mt, D)), self._new((Mt, D))     # backward temporaries
         self.t_qkv = self._new((Mt, 3 * D))
+        self._wg_items = None
+        if self.group_wgrad:
+            # every Linear's output gradient stays alive until the grouped weight-gradient launch: the gradient of the residual
+            # stream after each of a layer's two LayerNorm backwards (G1: at x1, G0: at x0), d(fc1 output), d(qkv)
+            for L in self.layers:
+                L["G1"], L["G0"] = self._new((B, self.N, D)), self._new((B, self.N, D))
+                L["t_b"], L["t_qkv"] = self._new((Mt, L["fc1"].out_features)), self._new((Mt, 3 * D))
         self.delta = self._f32(B * self.heads, self.N)
         self.row_part = self._f32(self.o.rowslab_rows(Mt), 2 * D)
         mlp = self.layers[0]["fc1"].out_features
@@ -574,41 +590,69 @@ class Engine:
             self.o.pose_head_bwd(xl, pw.weight, dhm, G, self._pair(pw.weight, pw.bias), self.pose_slab, self.fh, self.fw)
         self.o.cls_head_bwd(dlogits, head[1].weight, head[0].weight, head[0].bias, self.cls_xhat, self.cls_mr, G,
                             g(head[1].weight), g(head[1].bias), self._pair(head[0].weight, head[0].bias), self.cls_part)
+        grp = self.group_wgrad
         for i in reversed(range(len(self.layers))):
             L = self.layers[i]
             x0, x1 = self.x[2 * i].view(Mt, D), self.x[2 * i + 1].view(Mt, D)
             at, ff = L["attn"], L["ff"]
             fc1, fc2, ln2 = ff.net[1], ff.net[4], ff.net[0]
+            # grouped weight gradients: every output gradient into its own buffer (G1 / G0: the stream's gradient at x1 / x0)
+            t_b, t_qkv = (L["t_b"], L["t_qkv"]) if grp else (self.t_b, self.t_qkv)
+            G1, G0 = (L["G1"].view(Mt, D), L["G0"].view(Mt, D)) if grp else (Gm, Gm)
             # x2 = fc2(gelu(fc1(LN(x1)))) + x1
             defer = self.leaf_plan is not None
             if defer:
                 self.o.bias_grad(Gm, L["p_b2"], None)
             else:
                 self.o.bias_grad(Gm, self.row_part, g(fc2.bias))
-            self.o.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
+            if not grp:
+                self.o.linear_wgrad(L["hg"], Gm, g(fc2.weight), self.wgrad_ws)
             if self.fuse_gelu_bwd:
                 # d a = (G @ fc2.W) * gelu'(a) and fc1's bias gradient (its column sums) in one launch
-                self.o.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], self.t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
+                self.o.linear_gelu_bwd(Gm, L["fc2_wd"], L["a"], t_b, L["p_gelu"] if defer else self.gelu_part, self.gelu_tiles,
                                     None if defer else g(fc1.bias))
             else:
                 self.o.linear_fwd(Gm, L["fc2_wd"], self.t_a)                   # d hgelu
-                self.o.gelu_bwd(self.t_a, L["a"], self.t_b)                    # d a
-                self.o.bias_grad(self.t_b, self.row_part, g(fc1.bias))
-            self.o.linear_wgrad(L["xn2"], self.t_b, g(fc1.weight), self.wgrad_ws)
-            self.o.linear_fwd(self.t_b, L["fc1_wd"], self.t_a)                 # d xn2
-            self.o.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, Gm, L["p_ln2"] if defer else self.row_part,
+                self.o.gelu_bwd(self.t_a, L["a"], t_b)                         # d a
+                self.o.bias_grad(t_b, self.row_part, g(fc1.bias))
+            if not grp:
+                self.o.linear_wgrad(L["xn2"], t_b, g(fc1.weight), self.wgrad_ws)
+            self.o.linear_fwd(t_b, L["fc1_wd"], self.t_a)                      # d xn2
+            self.o.layernorm_bwd(self.t_a, x1, L["mr2"], ln2.weight, G1, L["p_ln2"] if defer else self.row_part,
                               None if defer else self._pair(ln2.weight, ln2.bias), dres=Gm)
             # x1 = to_out(attention(LN(x0))) + x0
-            self.o.linear_wgrad(L["ao"], Gm, g(at.to_out.weight), self.wgrad_ws)
-            self.o.linear_fwd(Gm, L["out_wd"], self.t_a)                       # d ao
-            self.o.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, self.t_qkv, B, N, Hh, self.hd, at.scale)
-            self.o.linear_wgrad(L["xn"], self.t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
-            self.o.linear_fwd(self.t_qkv, L["qkv_wd"], self.t_a)               # d xn
-            self.o.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, Gm, L["p_ln1"] if defer else self.row_part,
-                              None if defer else self._pair(at.norm.weight, at.norm.bias), dres=Gm)
-        self.o.tokens_bwd(G, self.g_feat, g(dec.cls_token))
+            if not grp:
+                self.o.linear_wgrad(L["ao"], G1, g(at.to_out.weight), self.wgrad_ws)
+            self.o.linear_fwd(G1, L["out_wd"], self.t_a)                       # d ao
+            self.o.attention_bwd(L["qkvb"], L["ao"], self.t_a, L["lse"], self.delta, t_qkv, B, N, Hh, self.hd, at.scale)
+            if not grp:
+                self.o.linear_wgrad(L["xn"], t_qkv, g(at.to_qkv.weight), self.wgrad_ws)
+            self.o.linear_fwd(t_qkv, L["qkv_wd"], self.t_a)                    # d xn
+            self.o.layernorm_bwd(self.t_a, x0, L["mr1"], at.norm.weight, G0, L["p_ln1"] if defer else self.row_part,
+                              None if defer else self._pair(at.norm.weight, at.norm.bias), dres=G1)
+            Gm = G0
+        self.o.tokens_bwd(Gm.view(B, N, D), self.g_feat, g(dec.cls_token))
+        if grp:
+            self._vit_weight_grads()
         if self.leaf_plan is not None:
             self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches
+
+    def _vit_weight_grads(self):
+        """to_qkv / to_out / fc1 / fc2 `.weight.grad` of every Transformer layer (model/transformer.py:44,58-60) in one grouped launch
+        over the forward inputs and the per-layer output gradients vit_backward left in place."""
+        key = self._g(self.layers[0]["attn"].to_qkv.weight).data_ptr()
+        if self._wg_items is None or self._wg_items[0] != key:
+            Mt, D, probs = self.B * self.N, self.dim, []
+            for i, L in enumerate(self.layers):
+                at, ff = L["attn"], L["ff"]
+                top = self.G if i + 1 == len(self.layers) else self.layers[i + 1]["G0"]     # the stream's gradient at this layer's output
+                probs += [(L["hg"], top.view(Mt, D), self._g(ff.net[4].weight)), (L["xn2"], L["t_b"], self._g(ff.net[1].weight)),
+                          (L["ao"], L["G1"].view(Mt, D), self._g(at.to_out.weight)), (L["xn"], L["t_qkv"], self._g(at.to_qkv.weight))]
+            items, M = self.o.wgrad_group_items(probs)
+            assert 0 < self.o.linear_wgrad_group_workspace_bytes(self.dt, items, M) <= self.wgrad_ws.numel() * 4
+            self._wg_items = (key, items, M)
+        _, items, M = self._wg_items
+        self.o.linear_wgrad_group(items, M, self.wgrad_ws, self.dt)
 
     def _ready(self, tag):
         if self.on_grads_ready is not None:

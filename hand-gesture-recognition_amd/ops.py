@@ -250,6 +250,39 @@ def linear_wgrad(x, dy, dw, workspace, mode=None):
              workspace.numel() * workspace.element_size(), dtype_code(x, mode), M, N, K, _stream(x))
 
 
+def wgrad_group_items(problems):
+    """[(x [M,K], dy [M,N], dw f32 [N,K]), ...] -> the mtn_wgrad_item array mtn_linear_wgrad_group takes.  The tensors' storage must
+    stay where it is for as long as the array is used (a plan builds it once over its preallocated buffers)."""
+    arr = (lib.WgradItem * len(problems))()
+    M = None
+    for it, (x, dy, dw) in zip(arr, problems):
+        K, N = x.shape[-1], dy.shape[-1]
+        m = x.numel() // K
+        if M is None:
+            M = m
+        if m != M or dy.numel() // N != M or tuple(dw.shape) != (N, K) or dw.dtype != torch.float32 or not dw.is_contiguous() or dy.dtype != x.dtype:
+            raise ValueError("wgrad_group_items: problems must share the row count; dw must be a contiguous f32 [N, K]")
+        (it.x, it.ldx), (it.dy, it.lddy) = _rows(x), _rows(dy)
+        it.dw, it.N, it.K = dw.data_ptr(), N, K
+    return arr, M
+
+
+def linear_wgrad_group_workspace_bytes(dtype, items, M, mode=None):
+    """`items`: the array of wgrad_group_items, or just the problems' [(N, K), ...] (sizing a workspace before the buffers exist)"""
+    if isinstance(items, (list, tuple)):
+        arr = (lib.WgradItem * len(items))()
+        for it, (N, K) in zip(arr, items):
+            it.N, it.K = N, K
+        items = arr
+    return lib.call("mtn_linear_wgrad_group_workspace_bytes", code_of(dtype, mode), M, _C.addressof(items), len(items))
+
+
+def linear_wgrad_group(items, M, workspace, dtype, mode=None):
+    """dw_i[N_i,K_i] = dy_i[M,N_i]^T @ x_i[M,K_i] for every problem of `items` (wgrad_group_items) in one launch + one split sum."""
+    lib.call("mtn_linear_wgrad_group", _C.addressof(items), len(items), M, workspace.data_ptr(),
+             workspace.numel() * workspace.element_size(), code_of(dtype, mode), _stream(workspace))
+
+
 def slab_rows(rows):
     return lib.call("mtn_slab_rows", rows)
 

@@ -154,6 +154,22 @@ int mtn_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, 
 size_t mtn_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
 int mtn_linear_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                      size_t ws_bytes, int dtype, int M, int N, int K, void* stream);
+/* (ABI 7) the Linear weight gradients of a whole backward pass -- the `.weight.grad` of every nn.Linear of the four Transformer
+ * layers (model/transformer.py:44,58-60: to_qkv, to_out, the two FeedForward Linears), which autograd produces one by one --
+ * as ONE launch plus one split sum: dw_i[N_i][K_i] = dy_i[M][N_i]^T x_i[M][K_i], i < count, all over the same M rows.
+ * Nothing downstream reads a weight gradient before the optimizer step, so the caller keeps every (x_i, dy_i) alive until
+ * this call.  Results are written (not accumulated); the split sums run in a fixed order.  Groups the kernel cannot take in one
+ * launch (a side that is no multiple of 128) run as `count` mtn_linear_wgrad launches on the same workspace; more than 16
+ * problems run 16 at a time. */
+typedef struct mtn_wgrad_item {
+    const void* x;  int ldx;      /* [M][ldx]  forward input, K_i columns used */
+    const void* dy; int lddy;     /* [M][lddy] output gradient, N_i columns used */
+    float* dw;                    /* [N_i][K_i] f32 */
+    int N, K;
+} mtn_wgrad_item;
+size_t mtn_linear_wgrad_group_workspace_bytes(int dtype, int M, const mtn_wgrad_item* items, int count);
+int mtn_linear_wgrad_group(const mtn_wgrad_item* items, int count, int M, void* workspace, size_t ws_bytes, int dtype,
+                           void* stream);
 
 /* ---- train-mode BatchNorm2d + SiLU (+ residual)  (model/gelan.py:46,56,78-87) -------------------
  * Slabs of f32 partial sums ([rows][W]) are reduced in row order by the library; a slab that the
@@ -343,6 +359,7 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  *          key 28 = 0: f32 partial tiles in the split-K workspace of the bf16 mode (default: bf16 tiles, summed in f32);
  *          key 29 = 0: the narrow step of the 3x3 window weight gradient for every map -- 128 slots bf16, 64 split storage
  *                      (default: 256 for bf16 maps up to 48 wide, 128 for split-storage maps up to 24 wide);
+ *          key 30 = 0: mtn_linear_wgrad_group runs its problems one launch each;
  *          key 8 = 7 / 8: the 256x64 window tile of the 64-channel 3x3 layers whatever the row count / never.
  * Every key is refused (MTN_ERR_UNSUPPORTED, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
  * call into the library: the product path has no mutable configuration.

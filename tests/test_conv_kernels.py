@@ -467,6 +467,52 @@ def test_linear_wgrad_large_m(be, dtype):
     assert rel_err(dw, ref) < tol(dtype, 1e-4, 1e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    (300, [(768, 256), (256, 256), (512, 256), (256, 512)], 0),          # the four Linears of a Transformer layer, ragged row count
+    (70, [(128, 128), (256, 128), (128, 384)], 0),                       # fewer rows than one split step would like
+    (1100, [(256, 256), (128, 256)] * 3, 0),                             # several splits per tile
+    (1100, [(256, 256), (128, 256)] * 3, 24),                            # a slot budget below the tile count: one split, several rounds
+    (300, [(256, 256), (64, 256), (256, 128)], 0),                       # a 64-wide side: the library runs the problems one by one
+    (200, [(128, 128)] * 18, 0),                                         # more than 16 problems: two launches
+])
+def test_linear_wgrad_group(be, dtype, cfg):
+    """mtn_linear_wgrad_group: several Linear weight gradients over the same rows in one launch + one split sum -- against
+    torch, and against the one-launch-per-problem path (debug key 30 = 0); operands are slices of wider buffers (row pitch >
+    row length) as the plan's qkv / hidden buffers are."""
+    M, shapes, slots = cfg
+    d = be.device
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        xw, dyw = _rand((M, K + 128), dtype, 100 + i), _rand((M, N + 64), dtype, 200 + i)
+        x, dy = A(xw).to(d)[:, 64:64 + K], A(dyw).to(d)[:, 32:32 + N]                 # (multiples of 32 channels: valid split-storage slices)
+        refs.append(dyw[:, 32:32 + N].float().t() @ xw[:, 64:64 + K].float())
+        probs.append((x, dy, torch.full((N, K), float("nan"), device=d)))
+    got = []
+    for key in (1, 0):
+        dbg(30, key)
+        dbg(10, slots)
+        dbg(28, 0)               # (f32 partial tiles: the two paths then differ by summation order only)
+        try:
+            for _, _, dw in probs:
+                dw.fill_(float("nan"))
+            items, m = ops.wgrad_group_items(probs)
+            assert m == M
+            nbytes = ops.linear_wgrad_group_workspace_bytes(dtype, items, M)
+            assert nbytes > 0
+            ws = torch.empty(nbytes // 4 + 1, device=d)
+            ops.linear_wgrad_group(items, M, ws, dtype)
+            be.sync()
+            got.append([dw.cpu().clone() for _, _, dw in probs])
+        finally:
+            dbg(30, 1)
+            dbg(10, 0)
+            dbg(28, 1)
+    for a, b, ref in zip(got[0], got[1], refs):
+        assert rel_err(a, ref) < tol(dtype, 1e-4, 1e-2)
+        assert rel_err(a, b) < 1e-5
+
+
 def test_linear_wgrad_rows_beyond_2_16(be):
     """BASELINE config 4 (384x384: 577 tokens x B=128 = 73,856 rows): the row count squared exceeds
     2^32, which the pixel walk of the convolution path cannot index -- Linear must not go through it."""
