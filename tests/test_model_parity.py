@@ -84,6 +84,27 @@ def test_tiny_bf16x3_emu(golden_dir):
     _run(Backend("emu"), "tiny_b3_s32", golden_dir, "bf16x3", 1e-3, 3e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, "bf16x3", torch.bfloat16], ids=["f32", "x3", "bf16"])
+def test_grouped_weight_gradients_match_the_per_layer_plan(golden_dir, monkeypatch, dtype):
+    """The ViT's sixteen Linear weight gradients in one grouped launch at the end of its backward (the default plan) against
+    the plan that runs them one by one where autograd would (MTN_GROUP_WGRAD=0): every gradient of the model, same inputs."""
+    be = Backend("emu")
+    grads = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("MTN_GROUP_WGRAD", env)
+        g, sd, batch, model = _setup(be, "tiny_b3_s32", golden_dir, dtype)
+        img, label, target, tw = (t.to(be.device) for t in batch)
+        cls_out, hmap, _ = model(img)
+        assert model.engine(img.shape[0]).group_wgrad == (env == "1")
+        O.total_loss(cls_out, hmap, label, target, tw)[0].backward()
+        be.sync()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    for k in grads[0]:
+        # (the same products; the weight gradients are summed over another split of the rows: f32 sums of f32 partial tiles --
+        #  bf16 tiles in the bf16 mode, whose split count differs between the two plans)
+        assert rel_err(grads[0][k], grads[1][k]) < (2e-2 if dtype == torch.bfloat16 else 1e-5), k
+
+
 @pytest.mark.gpu
 def test_tiny_bf16_gpu(golden_dir):
     _run(Backend("hip"), "tiny_b3_s32", golden_dir, torch.bfloat16, 5e-2, 0.3)
