@@ -268,6 +268,47 @@ int mtn_linear_wgrad_group(const mtn_wgrad_item* items, int count, int M, void* 
     return MTN_OK;
 }
 
+// The weight gradients of `count` Conv2d(k=3, s=1, p=1) layers of ONE geometry -- the four 3x3 convolutions of a GELAN stage's
+// residual blocks (model/gelan.py:69-70,78-87) -- in one launch + one split sum (wgrad.hip, wgrad3_group_kernel).  Geometries
+// the window kernel does not serve (or more than MTN_WGRAD_GROUP_MAX problems) run as `count` mtn_conv_wgrad calls.  items[i].N / K
+// must be Cout / Cin.
+size_t mtn_conv_wgrad_group_workspace_bytes(int dtype, int count, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    const size_t one = mtn_conv_wgrad_workspace_bytes(dtype, B, H, W, Cin, Cout, ksize, stride);
+    if (!one || count <= 0) return 0;
+    const size_t grp = (ksize == 3 && stride == 1) ? mtn_wgrad3_group_bytes(B, H, W, Cout, Cin, dtype, count < MTN_WGRAD_GROUP_MAX ? count : MTN_WGRAD_GROUP_MAX) : 0;
+    return grp > one ? grp : one;
+}
+
+int mtn_conv_wgrad_group(const mtn_wgrad_item* items, int count, void* workspace, size_t ws_bytes, int dtype, int B, int H, int W,
+                         int Cin, int Cout, int ksize, int stride, void* stream) {
+    MTN_REQUIRE(items && count > 0 && workspace, "conv_wgrad_group: bad arguments (count=%d)", count);
+    MTN_REQUIRE(ksize == 1 || ksize == 3, "conv_wgrad_group: ksize=%d", ksize);
+    MTN_REQUIRE(stride == 1 || stride == 2, "conv_wgrad_group: stride=%d", stride);
+    for (int i = 0; i < count; ++i)
+        MTN_REQUIRE(items[i].N == Cout && items[i].K == Cin, "conv_wgrad_group: problem %d is %d x %d, the geometry says %d x %d", i, items[i].N, items[i].K, Cout, Cin);
+    for (int i0 = 0; i0 < count; i0 += MTN_WGRAD_GROUP_MAX) {
+        const int n = count - i0 < MTN_WGRAD_GROUP_MAX ? count - i0 : MTN_WGRAD_GROUP_MAX;
+        int sps = 0;
+        if (ksize == 3 && stride == 1 && mtn_wgrad3_group_splits(B, H, W, Cout, Cin, dtype, n, &sps) > 0) {
+            WgradGroupArgs g{};
+            g.count = n;
+            for (int i = 0; i < n; ++i) {
+                const mtn_wgrad_item& it = items[i0 + i];
+                g.item[i].dY = it.dy; g.item[i].lddy = it.lddy; g.item[i].X = it.x; g.item[i].ldx = it.ldx; g.item[i].dW = it.dw;
+            }
+            const int rc = mtn_wgrad3_group_run(g, dtype, B, H, W, Cin, Cout, workspace, ws_bytes, (hipStream_t)stream);
+            if (rc) return rc;
+            continue;
+        }
+        for (int i = 0; i < n; ++i) {
+            const mtn_wgrad_item& it = items[i0 + i];
+            const int rc = mtn_conv_wgrad(it.x, it.ldx, it.dy, it.lddy, it.dw, workspace, ws_bytes, dtype, B, H, W, Cin, Cout, ksize, stride, stream);
+            if (rc) return rc;
+        }
+    }
+    return MTN_OK;
+}
+
 int mtn_conv1_stats_tiles(int B, int H, int W) { return mtn_conv1_tiles((long)B * (H / 2) * (W / 2)); }
 
 int mtn_conv1_fwd(const float* x_nchw, const void* w, void* y, float* stats, int dtype, int B, int H, int W,

@@ -92,6 +92,9 @@ int mtn_wgrad_group_plan(int dtype, int M, const int* N, const int* K, int count
 size_t mtn_wgrad_group_bytes(int dtype, int M, const int* N, const int* K, int count);
 int mtn_wgrad_group_run(WgradGroupArgs& g, int dtype, int M, void* workspace, size_t ws_bytes, hipStream_t stream);
 void mtn_wgrad_set_group(int on);
+int mtn_wgrad3_group_splits(int B, int H, int W, int N, int Cin, int dtype, int count, int* slots_per_split);
+size_t mtn_wgrad3_group_bytes(int B, int H, int W, int N, int Cin, int dtype, int count);
+int mtn_wgrad3_group_run(WgradGroupArgs& g, int dtype, int B, int H, int W, int Cin, int N, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mtn_wgrad_splits(int M, int N, int K, int Cin, int dtype, int* rows_per_split);
 int mtn_wgrad_run(const WgradArgs& p, int dtype, hipStream_t stream);
 void mtn_wgrad_set_tr16(int on);

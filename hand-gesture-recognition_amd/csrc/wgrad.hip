@@ -675,8 +675,10 @@ template <class T> struct Wg3 {
 // KSX / WMAX (round 5): slots per step and the widest map the two stages are sized for -- 256 slots per step for bf16 maps up to
 // 48 wide (2 x 79 KB of stages): halo 1.39x instead of 1.78x of the step's slots, half the barriers and DMA batches per slot
 // (68-72 us per layer instead of 72-79, step -0.02 ms: profiles/r05_misc_ab.txt)
-template <class T, int KSX = Wg3<T>::KS, int WMAX = Wg3<T>::MAXW>
-__global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
+// (the body takes the workgroup's index in its problem's grid and that grid's size: wgrad3_group_kernel runs several problems
+//  in one launch)
+template <class T, int KSX, int WMAX>
+__device__ __forceinline__ void wgrad3_body(const WgradArgs& p, const int L, const int nwg) {
     constexpr int KS = KSX, VEC = Wg3<T>::VEC, CPR = Wg3<T>::CPR, RPB = Wg3<T>::RPB;
     constexpr int STG = (2 * KS + 2 * (WMAX + 2) + RPB) * 64;
     constexpr int KI = Mma<T>::KI;
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
     const int tiles_n = p.N / 64, tiles = tiles_n * (p.Cin / 64);
     int tile, split;
     {
-        const int L = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
         const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
         split = lin / tiles;
         tile = lin - split * tiles;
@@ -876,6 +878,27 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
         }
 }
 
+template <class T, int KSX = Wg3<T>::KS, int WMAX = Wg3<T>::MAXW>
+__global__ __launch_bounds__(512) void wgrad3_kernel(WgradArgs p) {
+    wgrad3_body<T, KSX, WMAX>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The 3x3 stride-1 weight gradients of ONE stage (its four residual-block convolutions: same map, same channel counts) in one
+// launch (round 5).  Each alone fills the 256 CUs with splits of ~10 window steps and a 147 KB partial tile per workgroup
+// (580-630 TFLOP/s); at four times the batch the same kernel runs at 710-770 TFLOP/s (tools/probes/wgrad3_scaling.py), which is
+// what four problems sharing the CUs get: a quarter of the splits, four times the steps per workgroup, a quarter of the slab.
+template <class T, int KSX, int WMAX>
+__global__ __launch_bounds__(512) void wgrad3_group_kernel(WgradGroupArgs g) {
+    const int L = (int)blockIdx.x;
+    int prob = 0;
+    for (int i = 1; i < g.count; ++i) prob += L >= g.first[i] ? 1 : 0;
+    const WgradArgs p = g.item[prob];
+    const int l = L - g.first[prob];
+    const int nwg = (p.N / 64) * (p.Cin / 64) * p.splits;         // (the range is padded to a multiple of 8 workgroups)
+    if (l >= nwg) return;
+    wgrad3_body<T, KSX, WMAX>(p, l, nwg);
+}
+
 // dW_oihw[o][ci][kh][kw] = sum_s partial[s][o][(kh*KW+kw)*Cin + ci]
 // block = 8 split lanes x 32 columns of FOUR consecutive elements: 16-byte loads, several in flight per
 // thread (the first version read 4 bytes per lane with one load in flight: 3 TB/s on a slab that sits in
@@ -919,7 +942,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradGroupArgs 
     int prob = 0;
     for (int i = 1; i < g.count; ++i) prob += L >= g.rfirst[i] ? 1 : 0;
     const WgradArgs p = g.item[prob];
-    wgrad_reduce_body<PT>(reinterpret_cast<const PT*>(p.partial), p.dW, p.splits, p.N, p.K, p.Cin, 1, L - g.rfirst[prob]);
+    wgrad_reduce_body<PT>(reinterpret_cast<const PT*>(p.partial), p.dW, p.splits, p.N, p.K, p.Cin, p.KH * p.KW, L - g.rfirst[prob]);
 }
 
 template <class T, int BN, int BC, int WGM, int WGN, bool TR>
@@ -1011,6 +1034,24 @@ int launch_wgrad3(const WgradArgs& p, hipStream_t stream) {
     }
     MTN_LAUNCH(wgrad3_kernel<T>, dim3(tiles * p.splits), dim3(512), 0, stream, p);
     return mtn_check_launch("wgrad3");
+}
+
+template <class T>
+int launch_wgrad3_group(const WgradGroupArgs& g, int blocks, int W, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2) {
+        if (mtn_wgrad3_ks(MTN_BF16, W) == 256) {
+            MTN_LAUNCH((wgrad3_group_kernel<T, 256, 48>), dim3(blocks), dim3(512), 0, stream, g);
+            return mtn_check_launch("wgrad3_group");
+        }
+    }
+    if constexpr (std::is_same<T, f32x3_t>::value) {
+        if (mtn_wgrad3_ks(MTN_F32X3, W) == 128) {
+            MTN_LAUNCH((wgrad3_group_kernel<T, 128, 24>), dim3(blocks), dim3(512), 0, stream, g);
+            return mtn_check_launch("wgrad3_group");
+        }
+    }
+    MTN_LAUNCH((wgrad3_group_kernel<T, Wg3<T>::KS, Wg3<T>::MAXW>), dim3(blocks), dim3(512), 0, stream, g);
+    return mtn_check_launch("wgrad3_group");
 }
 
 }  // namespace
@@ -1333,4 +1374,73 @@ size_t mtn_wgrad_group_bytes(int dtype, int M, const int* N, const int* K, int c
     size_t off = 0;
     for (int i = 0; i < count; ++i) off += ((size_t)splits * N[i] * K[i] * 4 + 255) / 256 * 256;
     return off;
+}
+
+// ---- grouped 3x3 stride-1 weight gradients (wgrad3_group_kernel): `count` problems of ONE geometry ------------------------------
+// split of the padded slot axis of each problem: all tiles of all problems x splits = one workgroup per CU (0: not groupable)
+int mtn_wgrad3_group_splits(int B, int H, int W, int N, int Cin, int dtype, int count, int* slots_per_split) {
+    if (!g_wgrad_group || count < 2 || count > MTN_WGRAD_GROUP_MAX || !mtn_wgrad3_ok(dtype, H, W, 3, 1) || N % 64 || Cin % 64) return 0;
+    const int ks = mtn_wgrad3_ks(dtype, W);
+    const long S = (long)B * (H + 1) * (W + 1);
+    const long tiles = (long)(N / 64) * (Cin / 64) * count;
+    long splits = (g_wgrad_slots > 0 ? g_wgrad_slots : 256) / tiles;
+    if (splits < 1) splits = 1;
+    const long max_splits = (S + ks - 1) / ks;
+    if (splits > max_splits) splits = max_splits;
+    long sps = (S + splits - 1) / splits;
+    sps = (sps + ks - 1) / ks * ks;
+    *slots_per_split = (int)sps;
+    return (int)((S + sps - 1) / sps);
+}
+
+size_t mtn_wgrad3_group_bytes(int B, int H, int W, int N, int Cin, int dtype, int count) {
+    int sps = 0;
+    const int splits = mtn_wgrad3_group_splits(B, H, W, N, Cin, dtype, count, &sps);
+    return splits ? (size_t)count * (((size_t)splits * N * 9 * Cin * 4 + 255) / 256 * 256) : 0;
+}
+
+// g.item[i]: dY / lddy / X / ldx / dW filled by the caller; the shared geometry and everything else here
+int mtn_wgrad3_group_run(WgradGroupArgs& g, int dtype, int B, int H, int W, int Cin, int N, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    MTN_REQUIRE(dtype == MTN_BF16 || dtype == MTN_F32 || dtype == MTN_F32X3, "wgrad3 group: bad dtype %d", dtype);
+    int sps = 0;
+    const int splits = mtn_wgrad3_group_splits(B, H, W, N, Cin, dtype, g.count, &sps);
+    MTN_REQUIRE(splits > 0, "wgrad3 group: the geometry is not served by the window kernel");
+    const unsigned w1 = (unsigned)W + 1u, h1 = (unsigned)H + 1u;
+    MTN_REQUIRE(((long)B * h1 * w1 + 4096) * w1 < (1L << 32), "wgrad3 group: too many slots for the multiply-high decode");
+    const size_t esz = dtype == MTN_BF16 ? 2 : 4;
+    const int slab_bf16 = (dtype == MTN_BF16 && g_wgrad_slab_bf16) ? 1 : 0;
+    const long M = (long)B * H * W;
+    size_t off = 0;
+    int blocks = 0, rblocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+        WgradArgs& p = g.item[i];
+        MTN_REQUIRE(p.dY && p.X && p.dW, "wgrad3 group: null operand in problem %d", i);
+        MTN_REQUIRE((((uintptr_t)p.dY | (uintptr_t)p.X) % 16) == 0 && p.lddy >= N && p.ldx >= Cin && p.lddy % 8 == 0 && p.ldx % 8 == 0,
+                    "wgrad3 group: operands must be 16-byte aligned rows of at least the channel count (problem %d)", i);
+        MTN_REQUIRE(dtype != MTN_F32X3 || (p.lddy % 32 == 0 && p.ldx % 32 == 0), "wgrad3 group: split storage needs row pitches that are multiples of 32");
+        MTN_REQUIRE(M * p.lddy < (1L << 30) && M * p.ldx < (1L << 30), "wgrad3 group: tensor too large for 32-bit byte offsets");
+        p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = H; p.OW = W; p.KH = p.KW = 3; p.stride = 1; p.pad = 1;
+        p.M = (int)M; p.N = N; p.K = 9 * Cin;
+        p.splits = splits; p.rows_per_split = sps; p.win = 1;
+        p.magic_ow = (unsigned)(0x100000000ull / w1) + 1u;
+        p.magic_oh = (unsigned)(0x100000000ull / h1) + 1u;
+        p.y_bytes = (unsigned)((((size_t)M - 1) * p.lddy + N) * esz);
+        p.x_bytes = (unsigned)((((size_t)M - 1) * p.ldx + Cin) * esz);
+        p.slab_bf16 = slab_bf16;
+        p.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
+        off += ((size_t)splits * N * p.K * (slab_bf16 ? 2 : 4) + 255) / 256 * 256;
+        g.first[i] = blocks;
+        blocks += ((N / 64) * (Cin / 64) * splits + 7) / 8 * 8;
+        g.rfirst[i] = rblocks;
+        rblocks += (int)(((long)N * p.K / 4 + 31) / 32);
+    }
+    g.first[g.count] = blocks;
+    g.rfirst[g.count] = rblocks;
+    MTN_REQUIRE(off <= ws_bytes, "wgrad3 group: workspace too small (%zu bytes, %zu needed)", ws_bytes, off);
+    int rc = dtype == MTN_BF16 ? launch_wgrad3_group<bf16_t>(g, blocks, W, stream)
+                               : (dtype == MTN_F32X3 ? launch_wgrad3_group<f32x3_t>(g, blocks, W, stream) : launch_wgrad3_group<float>(g, blocks, W, stream));
+    if (rc) return rc;
+    if (slab_bf16) MTN_LAUNCH(wgrad_reduce_group_kernel<bf16_t>, dim3(rblocks), dim3(256), 0, stream, g);
+    else MTN_LAUNCH(wgrad_reduce_group_kernel<float>, dim3(rblocks), dim3(256), 0, stream, g);
+    return mtn_check_launch("wgrad_reduce_group");
 }

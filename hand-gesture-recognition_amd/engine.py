@@ -72,6 +72,9 @@ class Engine:
         # the sixteen Linear weight gradients of the ViT as ONE grouped launch at the end of its backward (mtn_linear_wgrad_group):
         # their output gradients then live in per-layer buffers instead of the shared temporaries (MTN_GROUP_WGRAD=0: one launch each)
         self.group_wgrad = os.environ.get("MTN_GROUP_WGRAD", "1") != "0"
+        # ... and the four 3x3 weight gradients of each stage's residual blocks as one grouped launch at the end of the stage's
+        # backward (mtn_conv_wgrad_group; MTN_GROUP_WGRAD=vit: the ViT's only)
+        self.group_wgrad3 = os.environ.get("MTN_GROUP_WGRAD", "1") not in ("0", "vit")
         self._build()
 
     # ---------------------------------------------------------------- buffers
@@ -221,6 +224,21 @@ class Engine:
                 at, ff = L["attn"], L["ff"]
                 shapes += [tuple(w.shape) for w in (ff.net[4].weight, ff.net[1].weight, at.to_out.weight, at.to_qkv.weight)]
             max_ws = max(max_ws, self.o.linear_wgrad_group_workspace_bytes(self.dt, shapes, Mt))
+        # the 3x3 convolutions of a stage's residual blocks (one geometry per stage) share ONE grouped weight-gradient launch at the
+        # end of the stage's backward: their raw-output gradients stay alive in buffers of their own until then
+        for u in self.units:
+            u.dy_own, u.wgrad_x = None, None
+        for st in self.stages:
+            st["wg_units"], st["wg_items"] = [], None
+            if not self.group_wgrad3:
+                continue
+            us = [rb[k] for br in st["branches"] for rb in br for k in ("c1", "c2")]
+            u0 = us[0]
+            if len(us) >= 2 and all((u.k, u.s, u.cin, u.cout, u.hin, u.win) == (3, 1, u0.cin, u0.cout, u0.hin, u0.win) for u in us):
+                st["wg_units"] = us
+                max_ws = max(max_ws, self.o.conv_wgrad_group_workspace_bytes(self.dt, len(us), B, u0.hin, u0.win, u0.cin, u0.cout, 3, 1))
+                for u in us:
+                    u.dy_own = self._new((B, u.hout, u.wout, u.cout))
         self.dyraw = self._new((max_dy,))
         self.bn_part = self._f32(max_part)
         self.wgrad_ws = self._f32(max_ws // 4 + 4)
@@ -332,6 +350,8 @@ class Engine:
         self.pack_weights(folded=True)
 
     def _dy(self, u):
+        if u.dy_own is not None:        # (a unit whose weight gradient waits for its stage's grouped launch)
+            return u.dy_own
         return self.dyraw[:u.M * u.cout].view(self.B, u.hout, u.wout, u.cout)
 
     def _bn_fwd(self, u, out, res=None):
@@ -376,7 +396,10 @@ class Engine:
             self.o.bn_act_bwd(g_out, u.raw, res, u.ss, u.mr, self.bn_part, u.coef, self._g(bn.weight), self._g(bn.bias),
                               dy, _ACT[u.act or res is not None], dres=dres, extra=dres if dres_accumulate else None,
                               partial_rows=rows)
-        self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
+        if u.dy_own is None:
+            self.o.conv_wgrad(x, dy, self._g(u.weight), self.wgrad_ws, u.k, u.s)
+        else:
+            u.wgrad_x = x               # its stage's grouped launch (_stage_weight_grads) reads x and dy_own
         if g_in is not None:
             self._dgrad(u, dy, g_in, g_in_res, nxt)
 
@@ -543,6 +566,7 @@ class Engine:
             self._conv_bwd(st["cv1"], gc[..., :C], st["in"], g_in,
                            nxt=(self.u_conv2 if si == 0 else self.stages[si - 1]["down"], None))
             g_cur = g_in
+            self._stage_weight_grads(st)
             self._ready(("stage", self.stages.index(st)))
         self._conv_bwd(self.u_conv2, self.g_a2, self.a1, self.g_a1)
         u1, bn = self.u_conv1, self.u_conv1.mod.bn
@@ -636,6 +660,18 @@ class Engine:
             self._vit_weight_grads()
         if self.leaf_plan is not None:
             self.leaf_plan.run()                                        # all LayerNorm / bias gradients of the ViT: two launches
+
+    def _stage_weight_grads(self, st):
+        """`.weight.grad` of the 3x3 convolutions of a stage's residual blocks (model/gelan.py:69-70) in one grouped launch over the
+        inputs and raw-output gradients their _conv_bwd calls left in place."""
+        us = st["wg_units"]
+        if not us:
+            return
+        key = self._g(us[0].weight).data_ptr()
+        if st["wg_items"] is None or st["wg_items"][0] != key:
+            st["wg_items"] = (key, self.o.conv_wgrad_group_items([(u.wgrad_x, u.dy_own, self._g(u.weight)) for u in us]))
+        u = us[0]
+        self.o.conv_wgrad_group(st["wg_items"][1], self.wgrad_ws, self.dt, self.B, u.hin, u.win, u.cin, u.cout, 3, 1)
 
     def _vit_weight_grads(self):
         """to_qkv / to_out / fc1 / fc2 `.weight.grad` of every Transformer layer (model/transformer.py:44,58-60) in one grouped launch

@@ -31,6 +31,8 @@ _PROTOS = {
     "mtn_linear_wgrad": [_vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mtn_linear_wgrad_group_workspace_bytes": [_i, _i, _vp, _i],
     "mtn_linear_wgrad_group": [_vp, _i, _i, _vp, _sz, _i, _vp],
+    "mtn_conv_wgrad_group_workspace_bytes": [_i] * 9,
+    "mtn_conv_wgrad_group": [_vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mtn_conv1_stats_tiles": [_i, _i, _i],
     "mtn_conv1_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mtn_conv1_wgrad_partial_rows": [_i, _i, _i],
@@ -97,9 +99,9 @@ class WgradItem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("dy", C.c_void_p), ("lddy", C.c_int), ("dw", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
 
 
-_RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_group_workspace_bytes": _sz, "mtn_pose_slab_floats": _sz}
+_RESTYPES = {"mtn_conv_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_workspace_bytes": _sz, "mtn_linear_wgrad_group_workspace_bytes": _sz, "mtn_conv_wgrad_group_workspace_bytes": _sz, "mtn_pose_slab_floats": _sz}
 _STATUS_FREE = {"mtn_abi_version", "mtn_has_experiments", "mtn_debug_key_is_experiment", "mtn_conv_kernel_family", "mtn_colsum_rows_per_block", "mtn_colsum_direct_rows", "mtn_rowslab_producer_rows", "mtn_conv_stats_tiles", "mtn_conv_dgrad_bn_tiles", "mtn_conv_fwd_stats_tiles", "mtn_linear_gelu_bwd_tiles", "mtn_conv_wgrad_workspace_bytes",
-                "mtn_linear_wgrad_workspace_bytes", "mtn_linear_wgrad_group_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
+                "mtn_linear_wgrad_workspace_bytes", "mtn_linear_wgrad_group_workspace_bytes", "mtn_conv_wgrad_group_workspace_bytes", "mtn_slab_rows", "mtn_bn_bwd_partial_rows",
                 "mtn_conv1_stats_tiles", "mtn_conv1_wgrad_partial_rows", "mtn_rowslab_rows",
                 "mtn_conv1_bwd_partial_rows", "mtn_conv1_bwd_partial_width",
                 "mtn_loss_partial_len", "mtn_pose_slab_floats"}   # return a value, not a status

@@ -267,6 +267,28 @@ def wgrad_group_items(problems):
     return arr, M
 
 
+def conv_wgrad_group_items(problems):
+    """[(x [B,H,W,Cin] (a channel slice is fine), dy [B,OH,OW,Cout], dw f32 [Cout,Cin,k,k]), ...] of ONE geometry -> the
+    mtn_wgrad_item array of mtn_conv_wgrad_group (same lifetime rule as wgrad_group_items)."""
+    arr = (lib.WgradItem * len(problems))()
+    for it, (x, dy, dw) in zip(arr, problems):
+        if dw.dtype != torch.float32 or not dw.is_contiguous() or dy.dtype != x.dtype or x.shape != problems[0][0].shape or dy.shape != problems[0][1].shape:
+            raise ValueError("conv_wgrad_group_items: one geometry per group; dw must be a contiguous f32 [Cout, Cin, k, k]")
+        (it.x, it.ldx), (it.dy, it.lddy) = _rows(x), _rows(dy)
+        it.dw, it.N, it.K = dw.data_ptr(), dy.shape[-1], x.shape[-1]
+    return arr
+
+
+def conv_wgrad_group_workspace_bytes(dtype, count, B, H, W, Cin, Cout, ksize, stride, mode=None):
+    return lib.call("mtn_conv_wgrad_group_workspace_bytes", code_of(dtype, mode), count, B, H, W, Cin, Cout, ksize, stride)
+
+
+def conv_wgrad_group(items, workspace, dtype, B, H, W, Cin, Cout, ksize, stride, mode=None):
+    """the weight gradients of every problem of `items` (conv_wgrad_group_items; x [B,H,W,Cin]) in one launch + one split sum"""
+    lib.call("mtn_conv_wgrad_group", _C.addressof(items), len(items), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+             code_of(dtype, mode), B, H, W, Cin, Cout, ksize, stride, _stream(workspace))
+
+
 def linear_wgrad_group_workspace_bytes(dtype, items, M, mode=None):
     """`items`: the array of wgrad_group_items, or just the problems' [(N, K), ...] (sizing a workspace before the buffers exist)"""
     if isinstance(items, (list, tuple)):

@@ -167,6 +167,12 @@ typedef struct mtn_wgrad_item {
     float* dw;                    /* [N_i][K_i] f32 */
     int N, K;
 } mtn_wgrad_item;
+/* (ABI 7) ... and the weight gradients of `count` Conv2d(k=3, s=1, p=1) layers of ONE geometry -- the four 3x3 convolutions of the two
+ * residual blocks of a GELAN stage (model/gelan.py:69-70,78-87,127-142) -- likewise: items[i].N = Cout, items[i].K = Cin for every i.
+ * Other geometries run as `count` mtn_conv_wgrad launches inside the call. */
+size_t mtn_conv_wgrad_group_workspace_bytes(int dtype, int count, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int mtn_conv_wgrad_group(const mtn_wgrad_item* items, int count, void* workspace, size_t ws_bytes, int dtype, int B, int H, int W,
+                         int Cin, int Cout, int ksize, int stride, void* stream);
 size_t mtn_linear_wgrad_group_workspace_bytes(int dtype, int M, const mtn_wgrad_item* items, int count);
 int mtn_linear_wgrad_group(const mtn_wgrad_item* items, int count, int M, void* workspace, size_t ws_bytes, int dtype,
                            void* stream);
@@ -359,7 +365,7 @@ int mtn_normalize_image(const unsigned char* img_hwc_u8, float* out_nchw, int B,
  *          key 28 = 0: f32 partial tiles in the split-K workspace of the bf16 mode (default: bf16 tiles, summed in f32);
  *          key 29 = 0: the narrow step of the 3x3 window weight gradient for every map -- 128 slots bf16, 64 split storage
  *                      (default: 256 for bf16 maps up to 48 wide, 128 for split-storage maps up to 24 wide);
- *          key 30 = 0: mtn_linear_wgrad_group runs its problems one launch each;
+ *          key 30 = 0: mtn_linear_wgrad_group / mtn_conv_wgrad_group run their problems one launch each;
  *          key 8 = 7 / 8: the 256x64 window tile of the 64-channel 3x3 layers whatever the row count / never.
  * Every key is refused (MTN_ERR_UNSUPPORTED, "disabled") unless the process set MTN_ALLOW_DEBUG_KEYS=1 before its first
  * call into the library: the product path has no mutable configuration.

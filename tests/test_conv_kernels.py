@@ -513,6 +513,53 @@ def test_linear_wgrad_group(be, dtype, cfg):
         assert rel_err(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, k, problems, slot budget (debug key 10; 0 = default)
+    (2, 12, 12, 64, 64, 3, 4, 0),            # a stage's four 3x3 layers: one tile each
+    (1, 24, 24, 128, 64, 3, 3, 0),           # two input-channel tiles
+    (3, 5, 7, 64, 128, 3, 2, 0),             # odd map, two output tiles
+    (2, 12, 20, 64, 64, 3, 4, 16),           # four splits per problem: several window steps per workgroup
+    (2, 6, 6, 64, 64, 1, 3, 0),              # a geometry the window kernel does not serve: one launch per problem inside the call
+])
+def test_conv_wgrad_group(be, dtype, cfg):
+    """mtn_conv_wgrad_group: the weight gradients of several convolutions of one geometry in one launch + one split sum -- against
+    torch, and against one launch per problem (debug key 30 = 0).  The inputs are channel slices of a wider buffer, as the
+    concat slices the model's residual blocks read are."""
+    B, H, W, Cin, Cout, k, count, slots = cfg
+    d = be.device
+    probs, refs = [], []
+    for i in range(count):
+        xw = _rand((B, H, W, Cin + 64), dtype, 300 + i)
+        dy = _rand((B, H, W, Cout), dtype, 400 + i)
+        w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+        F.conv2d(xw[..., 32:32 + Cin].float().permute(0, 3, 1, 2), w, None, 1, k // 2).backward(dy.float().permute(0, 3, 1, 2))
+        refs.append(w.grad)
+        probs.append((A(xw).to(d)[..., 32:32 + Cin], A(dy).to(d), torch.full((Cout, Cin, k, k), float("nan"), device=d)))
+    got = []
+    for key in (1, 0):
+        dbg(30, key)
+        dbg(10, slots)
+        dbg(28, 0)               # (f32 partial tiles: the two paths then differ by summation order only)
+        try:
+            for _, _, dw in probs:
+                dw.fill_(float("nan"))
+            items = ops.conv_wgrad_group_items(probs)
+            nbytes = ops.conv_wgrad_group_workspace_bytes(dtype, count, B, H, W, Cin, Cout, k, 1)
+            assert nbytes > 0
+            ws = torch.empty(nbytes // 4 + 1, device=d)
+            ops.conv_wgrad_group(items, ws, dtype, B, H, W, Cin, Cout, k, 1)
+            be.sync()
+            got.append([dw.cpu().clone() for _, _, dw in probs])
+        finally:
+            dbg(30, 1)
+            dbg(10, 0)
+            dbg(28, 1)
+    for a, b, ref in zip(got[0], got[1], refs):
+        assert rel_err(a, ref) < tol(dtype, 1e-4, 1e-2)
+        assert rel_err(a, b) < 1e-5
+
+
 def test_linear_wgrad_rows_beyond_2_16(be):
     """BASELINE config 4 (384x384: 577 tokens x B=128 = 73,856 rows): the row count squared exceeds
     2^32, which the pixel walk of the convolution path cannot index -- Linear must not go through it."""
